@@ -1,0 +1,89 @@
+/*
+ * brush_oracle.h — CPU restatement of wartron/brush's splat-rasterizer hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under brush_amd/ may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the
+ * checker / reported CPU baseline, never as the product path.
+ *
+ * Parity status: PINNED against the reference's own golden vectors
+ *   crates/brush-render/test_cases/{tiny_case,basic_case}.safetensors at the tolerances of
+ *   crates/brush-render/src/render.rs:815-830 (tests/test_oracle_golden.py), and against the
+ *   sort / scan vectors of crates/brush-sort/src/lib.rs:164-265 and
+ *   crates/brush-prefix-sum/src/lib.rs:110-175.
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ * All arithmetic is f32 with no FMA contraction (compile with -ffp-contract=off); the
+ * transcendental functions the per-splat stages need (exp, log) are the deterministic
+ * polynomial forms of oracle/detmath.h so that the integer outputs (visible set, depth order,
+ * tile lists) can be compared bit-for-bit with the GPU path.
+ */
+#ifndef BRUSH_ORACLE_H
+#define BRUSH_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* crates/brush-render/src/shaders/helpers.wgsl:7-30 (28 words, viewmat column-major). */
+typedef struct OracleUniforms {
+    float viewmat[16];
+    float focal[2];
+    uint32_t img_size[2];
+    uint32_t tile_bounds[2];
+    float pixel_center[2];
+    uint32_t sh_degree;
+    uint32_t num_visible;
+    uint32_t total_splats;
+    uint32_t padding;
+} OracleUniforms;
+
+/* Host-memory mirror of RenderAux (crates/brush-render/src/lib.rs:20-33). */
+typedef struct OracleAux {
+    float *projected_splats;           /* [N,9]  first V rows valid (helpers.wgsl:33-43) */
+    uint32_t *num_intersections;       /* [1] */
+    uint32_t *num_visible;             /* [1] */
+    uint32_t *final_index;             /* [h,w] */
+    uint32_t *cum_tiles_hit;           /* [N] inclusive scan, tail == I */
+    uint32_t *tile_bins;               /* [ty,tx,2] */
+    uint32_t *compact_gid_from_isect;  /* [max_intersects] */
+    uint32_t *global_from_compact_gid; /* [N] tail filled with 0 */
+    uint32_t *tile_id_from_isect;      /* [max_intersects] sorted tile ids (debug/test aid) */
+    uint8_t *flip_risk;                /* [h,w] optional (may be NULL): 1 where a composite
+                                          threshold test was within 1e-5 relative of flipping */
+    uint32_t max_intersects;
+} OracleAux;
+
+/* crates/brush-sort/src/lib.rs:32-147 — stable argsort on the low 4*ceil(bits/4) key bits. */
+void oracle_radix_argsort(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t n,
+                          uint32_t sorting_bits, uint32_t *keys_out, uint32_t *vals_out);
+
+/* crates/brush-prefix-sum/src/lib.rs:17-102 — inclusive u32 scan. */
+void oracle_inclusive_scan(const uint32_t *in, uint32_t n, uint32_t *out);
+
+/* crates/brush-render/src/render.rs:55-323. out_img: float[h*w*4] or (raster_u32) uint32[h*w]. */
+int oracle_render_forward(const OracleUniforms *u, const float *means, const float *log_scales,
+                          const float *quats, const float *sh_coeffs, const float *raw_opac,
+                          uint32_t n, int raster_u32, void *out_img, OracleAux *aux);
+
+/* crates/brush-render/src/render.rs:468-626. All v_* are dense [N,..], zero for non-visible. */
+int oracle_render_backward(const OracleUniforms *u, const OracleAux *aux, const float *means,
+                           const float *log_scales, const float *quats, const float *raw_opac,
+                           uint32_t n, const float *out_img, const float *v_out, float *v_means,
+                           float *v_xy, float *v_scales, float *v_quats, float *v_sh,
+                           float *v_opac,
+                           /* optional compact-order intermediates (may be NULL): */
+                           float *v_xy_local, float *v_conics, float *v_colors);
+
+/* Deterministic elementary functions (oracle/detmath.h), exported for tests. */
+float oracle_det_expf(float x);
+float oracle_det_logf(float x);
+
+int oracle_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
