@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — forward+backward splat rasterizer throughput on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one
+rank per GPU over RCCL).  One "step" = one forward+backward pass of the hot path over one view
+per GPU (BASELINE.json metric: fwd+bwd ms/view & iters/s, 1 M splats @1080p), on the seeded
+synthetic cloud of SURVEY §8(d) S1 (render_bench.rs:32-133 distribution, seed 4), inputs resident
+in HBM before the timed region.  For N>1 each rank renders its own view of the replicated cloud
+and the dense parameter-gradient block is all-reduced (RCCL) inside the step;
+scaling is weak (per-GPU work fixed).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--splats", type=int, default=1 << 20)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--mean-mult", type=float, default=1.0, help="1.0 = 'base', 0.25 = 'dense' (render_bench.rs:24)")
+    ap.add_argument("--max-intersects", type=int, default=0, help="0 = reference default min(N*T, 128*65535)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=20, help="extra steps with stage events (untimed)")
+    return ap.parse_args()
+
+
+def synthetic_cloud(n, sh_degree, seed=4, mean_mult=1.0):
+    """Host-generated so that CPU and GPU see identical bits."""
+    from tests.helpers import synthetic_cloud as gen
+
+    return gen(n, sh_degree, seed=seed, mean_mult=mean_mult)
+
+
+def view_camera(rank, w, h):
+    """Rank 0 uses the reference bench camera (render_bench.rs:163-174); other ranks orbit it."""
+    import brush_amd
+
+    focal = brush_amd.fov_to_focal(math.pi * 0.5, w)
+    fov_x, fov_y = brush_amd.focal_to_fov(focal, w), brush_amd.focal_to_fov(focal, h)
+    ang = 0.35 * rank
+    # rotation about y by `ang`, camera placed 8 units behind the origin along its own -z
+    rot = [0.0, math.sin(ang / 2), 0.0, math.cos(ang / 2)]
+    pos = [-8.0 * math.sin(ang), 0.0, -8.0 * math.cos(ang)]
+    return brush_amd.Camera(pos, rot, fov_x, fov_y, (0.5, 0.5))
+
+
+def algorithmic_bytes(n, V, I, P, T, C, fwd_only=False):
+    """B = N(92+12C) + V(356+12C) + I(132+16p) + 56P + 24T, p = passes of 8 bits."""
+    p = max(1, math.ceil(max(1, math.ceil(math.log2(T + 1))) / 8))
+    if fwd_only:
+        return n * 40 + V * (212 + 12 * C) + I * (56 + 16 * p) + P * 20 + T * 16
+    return n * (92 + 12 * C) + V * (356 + 12 * C) + I * (132 + 16 * p) + P * 56 + T * 24
+
+
+# Algorithmic HBM bytes of ONE launch of each single-kernel stage.
+def stage_bytes(stage, n, V, I, P, T, C):
+    return {
+        "rasterize": I * 40 + P * 20 + T * 8,              # isect gid + record gather, img + final_index
+        "rasterize_bwd": I * (40 + 36) + P * 36 + T * 8,   # gather + 9 float atomics / (tile,splat); out,v_out,final
+        "project_bwd": n * 4 + V * (40 + 36 + 4) + n * (52 + 12 * C),
+        "project_visible": V * (4 + 40 + 12 * C + 4 + 36 + 4 + 4) + (n - V) * 4,
+    }[stage]
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+    n_gpus = world
+
+    import brush_amd
+    from brush_amd import render as R
+    from brush_amd.profiler import StageProfiler
+
+    n, w, h, deg = args.splats, args.width, args.height, args.sh_degree
+    C = (deg + 1) ** 2
+    cloud = synthetic_cloud(n, deg, mean_mult=args.mean_mult)
+    p = {k: torch.as_tensor(v, device=dev) for k, v in cloud.items()}
+    cam = view_camera(rank, w, h)
+    cap = args.max_intersects or None
+    # upstream gradient of mean(img) (render_bench.rs:180)
+    v_out = torch.full((h, w, 4), 1.0 / (4 * w * h), dtype=torch.float32, device=dev)
+    layout, total = R.grad_block_layout(n, C)
+    block = torch.empty(total, dtype=torch.float32, device=dev)
+    param_floats = layout["v_sh"][0] + layout["v_sh"][1]  # [means|scales|quats|opac|sh] contiguous prefix
+
+    def step():
+        out, aux, u = R._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"],
+                                      False, cap)
+        R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], C, out, v_out, block)
+        if world > 1:
+            dist.all_reduce(block[:param_floats])  # dense gradient block, sum over views
+        return aux
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        aux = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        aux = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = n_gpus * args.steps / elapsed  # whole-job views/s
+
+    V, I = aux.read_num_visible(), aux.read_num_intersections()
+    overflow = int(aux.overflow.item())
+    P, T = w * h, (-(-w // 16)) * (-(-h // 16))
+
+    # ---- per-stage device time (hipEvents on the op's stream), separate untimed steps ----
+    stage_ms = {}
+    with StageProfiler() as prof:
+        acc = None
+        for _ in range(max(1, args.profile_steps)):
+            step()
+            ms = prof.read_ms()
+            acc = ms if acc is None else {k: acc[k] + ms[k] for k in ms}
+        stage_ms = {k: v / max(1, args.profile_steps) for k, v in acc.items()}
+    dominant = max(("rasterize", "rasterize_bwd", "project_bwd", "project_visible"), key=lambda k: stage_ms[k])
+    dom_bytes = stage_bytes(dominant, n, V, I, P, T, C)
+    achieved = dom_bytes / (stage_ms[dominant] * 1e-3) / 1e9 if stage_ms[dominant] > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dominant)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(stage_ms[dominant], 5)}
+    B = algorithmic_bytes(n, V, I, P, T, C)
+    whole_path = {"algorithmic_bytes": int(B), "achieved_GBs": round(B / (ms_per_step * 1e-3) / 1e9, 2),
+                  "frac_of_hbm_peak": round(B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    # ---- CPU baseline: the oracle (a port), rank 0, N=1 only --------------------------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+
+        u_np = R.uniforms_to_numpy(aux)
+        v_np = v_out.cpu().numpy()
+        reps = max(1, args.cpu_reps)
+        tc = time.perf_counter()
+        for _ in range(reps):
+            o_out, o_aux = O.render_forward(u_np, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["sh"],
+                                            cloud["raw_opac"], max_intersects=aux.max_intersects)
+            O.render_backward(u_np, o_aux, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["raw_opac"],
+                              o_out, v_np)
+        cpu_s = (time.perf_counter() - tc) / reps
+        cpu_baseline = {"value": round(1.0 / cpu_s, 4), "unit": "views/s", "cores": O.num_threads(), "kind": "port",
+                        "sample": f"{reps} fwd+bwd passes of the same workload (CPU restatement of the reference "
+                                  f"algorithm, OpenMP; not wgpu/lavapipe), {cpu_s * 1e3:.0f} ms/view"}
+
+    if rank == 0:
+        line = {
+            "metric": "fwd+bwd views/s (train-iter rate of the rasterizer path), 1M splats @1080p",
+            "value": round(value, 3), "unit": "views/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"S1: {n} splats @{w}x{h}, SH degree {deg}, seed 4, mean_mult {args.mean_mult}, "
+                                   f"fwd+bwd per view", "views_per_step": n_gpus,
+                       "parallelism": f"view-sharded dp{n_gpus}" if n_gpus > 1 else "single GPU",
+                       "num_visible": V, "num_intersections": I, "max_intersects": aux.max_intersects,
+                       "overflow": overflow},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "whole_path": whole_path,
+            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

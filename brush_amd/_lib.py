@@ -1,0 +1,118 @@
+"""ctypes binding of include/brush_hip.h.  Fails loudly when libbrush_hip.so is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbrush_hip.so")
+
+BRUSH_OK = 0
+UNIFORM_WORDS = 28
+NUM_VISIBLE_WORD = 25
+TILE_WIDTH = 16
+PROJECTED_FLOATS = 9
+
+
+class BrushUniforms(C.Structure):
+    """helpers.wgsl:7-30"""
+    _fields_ = [
+        ("viewmat", C.c_float * 16),
+        ("focal", C.c_float * 2),
+        ("img_size", C.c_uint32 * 2),
+        ("tile_bounds", C.c_uint32 * 2),
+        ("pixel_center", C.c_float * 2),
+        ("sh_degree", C.c_uint32),
+        ("num_visible", C.c_uint32),
+        ("total_splats", C.c_uint32),
+        ("padding", C.c_uint32),
+    ]
+
+
+class BrushAux(C.Structure):
+    """Device-pointer mirror of RenderAux (crates/brush-render/src/lib.rs:20-33)."""
+    _fields_ = [
+        ("projected_splats", C.c_void_p),
+        ("uniforms_buffer", C.c_void_p),
+        ("num_intersections", C.c_void_p),
+        ("num_visible", C.c_void_p),
+        ("final_index", C.c_void_p),
+        ("cum_tiles_hit", C.c_void_p),
+        ("tile_bins", C.c_void_p),
+        ("compact_gid_from_isect", C.c_void_p),
+        ("global_from_compact_gid", C.c_void_p),
+        ("compact_from_global_gid", C.c_void_p),
+        ("overflow", C.c_void_p),
+        ("max_intersects", C.c_uint32),
+    ]
+
+
+class BrushError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# (name, restype, argtypes) for every symbol include/brush_hip.h declares.
+_P = C.c_void_p
+_SYMBOLS = [
+    ("brush_version", C.c_char_p, []),
+    ("brush_status_string", C.c_char_p, [C.c_int]),
+    ("brush_last_hip_error", C.c_int, []),
+    ("brush_default_max_intersects", C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("brush_radix_argsort_workspace_size", C.c_int, [C.c_uint32, C.POINTER(C.c_size_t)]),
+    ("brush_radix_argsort_u32", C.c_int,
+     [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_size_t, _P]),
+    ("brush_inclusive_scan_workspace_size", C.c_int, [C.c_uint32, C.POINTER(C.c_size_t)]),
+    ("brush_inclusive_scan_u32", C.c_int, [_P, _P, C.c_uint32, _P, C.c_size_t, _P]),
+    ("brush_fwd_workspace_size", C.c_int,
+     [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
+    ("brush_render_forward", C.c_int,
+     [C.POINTER(BrushUniforms), _P, _P, _P, _P, _P, C.c_uint32, C.c_int, _P, C.POINTER(BrushAux), _P,
+      C.c_size_t, _P]),
+    ("brush_bwd_workspace_size", C.c_int,
+     [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
+    ("brush_render_backward", C.c_int,
+     [C.POINTER(BrushUniforms), C.POINTER(BrushAux), _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P,
+      _P, _P, _P, C.c_size_t, _P]),
+    ("brush_profiler_create", C.c_int, [C.POINTER(_P)]),
+    ("brush_profiler_destroy", None, [_P]),
+    ("brush_profiler_attach", None, [_P]),
+    ("brush_profiler_read", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("brush_stage_name", C.c_char_p, [C.c_int]),
+]
+
+NUM_STAGES = 11
+
+SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
+
+
+def lib():
+    """Load libbrush_hip.so (after torch, so both share one HIP runtime) and bind symbols."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BrushError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C brush_amd/csrc`. brush_amd has no CPU fallback.")
+    import torch  # noqa: F401  (loads torch's libamdhip64.so first; same SONAME is then reused)
+
+    handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, restype, argtypes in _SYMBOLS:
+        fn = getattr(handle, name)  # AttributeError if the header and the library diverge
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != BRUSH_OK:
+        l = lib()
+        msg = l.brush_status_string(status).decode()
+        raise BrushError(f"{what} failed: {msg} (status {status}, hipError {l.brush_last_hip_error()})")
+
+
+def version() -> str:
+    return lib().brush_version().decode()

@@ -1,0 +1,85 @@
+// common.hpp — shared host/device helpers for libbrush_hip (gfx950 only, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/brush_hip.h"
+
+namespace brush {
+
+constexpr uint32_t kTileWidth = BRUSH_TILE_WIDTH;      // helpers.wgsl:1
+constexpr uint32_t kTileSize = kTileWidth * kTileWidth; // helpers.wgsl:3
+constexpr uint32_t kWave = 64;                          // CDNA wavefront
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+constexpr uint32_t kUniformWords = 28;
+constexpr uint32_t kNumVisibleWord = 25;                // render.rs:145-149
+
+// Records the failing hipError_t for brush_last_hip_error().
+void set_last_hip_error(int e);
+
+#define BRUSH_HIP_CHECK(expr)                                   \
+    do {                                                        \
+        hipError_t _e = (expr);                                 \
+        if (_e != hipSuccess) {                                 \
+            ::brush::set_last_hip_error((int)_e);               \
+            return BRUSH_ERR_HIP;                               \
+        }                                                       \
+    } while (0)
+
+#define BRUSH_LAUNCH_CHECK() BRUSH_HIP_CHECK(hipGetLastError())
+
+static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace (256-B aligned carve-outs).
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *p) : base(static_cast<char *>(p)) {}
+    template <typename T>
+    T *take(size_t count) {
+        off = align_up(off, 256);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t bytes() const { return align_up(off, 256); }
+};
+
+// ---- device-side wave helpers -------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---- internal launch API (one per translation unit) ----------------------------------
+// scan.hip
+size_t scan_workspace_bytes(uint32_t n);
+// Inclusive scan of in[0..n) -> out. If d_valid_n != nullptr, elements >= *d_valid_n read as 0.
+// If d_total != nullptr, the grand total (out[n-1]) is also written there, clamped to `cap`
+// with *d_overflow set when it exceeded cap (pass cap = 0xFFFFFFFF / nullptr to disable).
+hipError_t scan_launch(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_valid_n,
+                       uint32_t *d_total, uint32_t cap, uint32_t *d_overflow, void *ws,
+                       hipStream_t s);
+
+// radix_sort.hip
+size_t sort_workspace_bytes(uint32_t max_n);
+hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
+                       uint32_t *vals_out, const uint32_t *d_n, uint32_t max_n, uint32_t bits,
+                       void *ws, hipStream_t s);
+
+}  // namespace brush

@@ -1,0 +1,47 @@
+// internal.hpp — host-side launch functions, one group per translation unit.
+#pragma once
+#include "common.hpp"
+
+namespace brush {
+
+struct ViewParams;
+
+// project.hip
+hipError_t launch_init(const BrushUniforms &u, const BrushAux &aux, uint32_t num_tiles, hipStream_t s);
+size_t cull_block_count(uint32_t n);
+hipError_t launch_project_cull(const ViewParams &vp, const float *means, const float *log_scales,
+                               const float *quats, uint32_t *key_all, uint32_t *compact_from_global,
+                               uint32_t *block_counts, uint32_t *num_visible, uint32_t *uniforms_buffer,
+                               uint32_t *keys, uint32_t *gids, hipStream_t s);
+hipError_t launch_project_visible(const ViewParams &vp, const float *means, const float *log_scales,
+                                  const float *quats, const float *sh, const float *raw_opac,
+                                  const uint32_t *num_visible, uint32_t *global_from_compact,
+                                  uint32_t *compact_from_global, float *projected, uint32_t *tiles_hit,
+                                  hipStream_t s);
+hipError_t launch_map_intersects(const ViewParams &vp, const float *projected, const uint32_t *cum_tiles_hit,
+                                 const uint32_t *num_visible, uint32_t cap, uint32_t *tile_ids, uint32_t *gids,
+                                 hipStream_t s);
+hipError_t launch_tile_bin_edges(const uint32_t *sorted_tile_ids, const uint32_t *num_intersections,
+                                 uint32_t cap, uint32_t *tile_bins, hipStream_t s);
+
+// rasterize.hip
+hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
+                            const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
+                            const float *projected, int raster_u32, void *out_img, uint32_t *final_index,
+                            hipStream_t s);
+hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
+                                     const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
+                                     const float *projected, const uint32_t *final_index,
+                                     const float *out_img, const float *v_out, float *v_xy_local,
+                                     float *v_conics, float *v_colors, hipStream_t s);
+
+// project_bwd.hip
+hipError_t launch_project_backward(const ViewParams &vp, const float *means, const float *log_scales,
+                                   const float *quats, const float *raw_opac,
+                                   const uint32_t *compact_from_global, const float *v_xy_local,
+                                   const float *v_conics, const float *v_colors, float *v_means, float *v_xy,
+                                   float *v_scales, float *v_quats, float *v_sh, float *v_opac, hipStream_t s);
+hipError_t launch_zero_compact_grads(const uint32_t *num_visible, uint32_t n, float *v_xy_local,
+                                     float *v_conics, float *v_colors, hipStream_t s);
+
+}  // namespace brush

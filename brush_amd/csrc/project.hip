@@ -1,0 +1,330 @@
+// project.hip — per-splat forward stages: cull + depth key, order-preserving compaction,
+// visible-splat projection (conic / xy / SH colour / opacity / exact tile count), tile
+// intersection emission and tile bin edges.
+//
+// Replaces (paths relative to the reference checkout):
+//   ProjectSplats            crates/brush-render/src/shaders/project_forward.wgsl:15-68
+//   ProjectVisible           .../project_visible.wgsl:163-258
+//   MapGaussiansToIntersect  .../map_gaussian_to_intersects.wgsl:10-48
+//   GetTileBinEdges          .../get_tile_bin_edges.wgsl:15-42
+//   CreateDispatchBuffer     crates/brush-kernel/src/shaders/wg.wgsl:15-40 (not needed: kernels
+//                            read the device-side counts themselves and grid-stride)
+//
+// This translation unit is compiled with -ffp-contract=off: every integer decision (cull, tile
+// counts, tile lists) is a function of correctly rounded f32 operations in a fixed order, so
+// the visible set, depth order and per-tile lists are reproducible bit-for-bit.
+//
+// Differences from the reference by design:
+//   * compaction is order-preserving (ascending global id) instead of an atomicAdd slot
+//     (project_forward.wgsl:65), which makes equal-depth order deterministic;
+//   * a compact_from_global map is produced so the backward can write dense gradients once,
+//     coalesced, instead of zero-filling and scattering.
+// All kernels are HBM-streaming (roofline: HBM).
+#include "internal.hpp"
+#include "splat_math.hpp"
+
+#pragma clang fp contract(off)
+
+namespace brush {
+namespace {
+
+constexpr uint32_t kThreads = 256;
+
+// ---- init: uniforms buffer, counters, tile bins -----------------------------------------
+__global__ __launch_bounds__(kThreads) void k_init(BrushUniforms u, uint32_t *__restrict__ uniforms_buffer,
+                                                   uint32_t *__restrict__ num_intersections,
+                                                   uint32_t *__restrict__ overflow,
+                                                   uint32_t *__restrict__ tile_bins, uint32_t num_bin_words) {
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gtid < kUniformWords) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&u);
+        uniforms_buffer[gtid] = w[gtid];
+    }
+    if (gtid == 0) {
+        *num_intersections = 0;
+        *overflow = 0;
+    }
+    for (uint32_t i = gtid; i < num_bin_words; i += gridDim.x * blockDim.x) tile_bins[i] = 0;  // render.rs:241-244
+}
+
+// ---- ProjectSplats: cull + depth key ------------------------------------------------------
+// project_forward.wgsl:15-68.  One splat per lane; 40 B read, 8 B written per splat.
+__global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, const float *__restrict__ means,
+                                                           const float *__restrict__ log_scales,
+                                                           const float *__restrict__ quats,
+                                                           uint32_t *__restrict__ key_all,
+                                                           uint32_t *__restrict__ compact_from_global,
+                                                           uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t wave_cnt[kThreads / kWave];
+    const uint32_t g = blockIdx.x * kThreads + threadIdx.x;
+    bool visible = false;
+    float depth = 0.0f;
+    if (g < vp.total_splats) {
+        const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
+        float p_view[3];
+        to_view(vp, mean, p_view);
+        if (p_view[2] > 0.01f) {  // :32
+            const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
+                                    det_expf(log_scales[(size_t)g * 3 + 2])};
+            const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
+            const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+            float cov2d[3];
+            calc_cov2d(vp, p_view, scale, quat, cov2d);
+            const float det = cov2d[0] * cov2d[2] - cov2d[1] * cov2d[1];
+            if (!(det == 0.0f)) {  // :43
+                float conic[3], xy[2];
+                cov_to_conic(cov2d, conic);
+                project_pix(vp, p_view, xy);
+                const uint32_t radius = radius_from_conic(conic);
+                uint32_t bb[4];
+                get_tile_bbox(xy, radius, vp.tile_bounds, bb);
+                if ((bb[2] - bb[0]) != 0u && (bb[3] - bb[1]) != 0u) {  // :60
+                    visible = true;
+                    depth = p_view[2];
+                }
+            }
+        }
+        key_all[g] = visible ? __float_as_uint(depth) : kInvalid;
+        compact_from_global[g] = kInvalid;
+    }
+    const uint64_t b = __ballot(visible);
+    if (lane_id() == 0) wave_cnt[threadIdx.x / kWave] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// Exclusive scan of block_counts in place; total -> num_visible and uniforms_buffer[25].
+__global__ __launch_bounds__(1024) void k_cull_scan(uint32_t *__restrict__ block_counts, uint32_t num_blocks,
+                                                    uint32_t *__restrict__ num_visible,
+                                                    uint32_t *__restrict__ uniforms_buffer) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < num_blocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < num_blocks ? block_counts[i] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (lane_id() == 63) wave_tot[threadIdx.x / kWave] = incl;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (uint32_t w = 0; w < threadIdx.x / kWave; w++) off += wave_tot[w];
+        if (i < num_blocks) block_counts[i] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *num_visible = carry_s;
+        uniforms_buffer[kNumVisibleWord] = carry_s;
+    }
+}
+
+// Order-preserving compaction of (depth key, global id).
+__global__ __launch_bounds__(kThreads) void k_compact(uint32_t n, const uint32_t *__restrict__ key_all,
+                                                      const uint32_t *__restrict__ block_offsets,
+                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ gids) {
+    __shared__ uint32_t wave_cnt[kThreads / kWave];
+    const uint32_t g = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t key = g < n ? key_all[g] : kInvalid;
+    const bool visible = key != kInvalid;
+    const uint64_t b = __ballot(visible);
+    const uint32_t wid = threadIdx.x / kWave;
+    if (lane_id() == 0) wave_cnt[wid] = __popcll(b);
+    __syncthreads();
+    if (visible) {
+        uint32_t off = block_offsets[blockIdx.x] + __popcll(b & lanemask_lt());
+        for (uint32_t w = 0; w < wid; w++) off += wave_cnt[w];
+        keys[off] = key;
+        gids[off] = g;
+    }
+}
+
+// ---- ProjectVisible ----------------------------------------------------------------------
+// project_visible.wgsl:163-258.  One visible splat per lane (compact = depth order), gathers
+// its parameters by global id; writes ProjectedSplat (36 B), the exact tile count, and the
+// inverse map.  Lanes c >= V clear the tail of global_from_compact_gid.
+__global__ __launch_bounds__(kThreads) void k_project_visible(
+    ViewParams vp, const float *__restrict__ means, const float *__restrict__ log_scales,
+    const float *__restrict__ quats, const float *__restrict__ sh_coeffs, const float *__restrict__ raw_opac,
+    const uint32_t *__restrict__ num_visible, uint32_t *__restrict__ global_from_compact,
+    uint32_t *__restrict__ compact_from_global, float *__restrict__ projected, uint32_t *__restrict__ tiles_hit) {
+    const uint32_t V = *num_visible;
+    const uint32_t n = vp.total_splats;
+    const uint32_t ncoef = (vp.sh_degree + 1) * (vp.sh_degree + 1);
+    for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < n; c += gridDim.x * kThreads) {
+        if (c >= V) {
+            global_from_compact[c] = 0;
+            continue;
+        }
+        const uint32_t g = global_from_compact[c];
+        compact_from_global[g] = c;
+        const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
+        const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
+                                det_expf(log_scales[(size_t)g * 3 + 2])};
+        const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
+        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float opac = det_sigmoid(raw_opac[g]);
+        float p_view[3], cov2d[3], conic[3], xy[2];
+        to_view(vp, mean, p_view);
+        calc_cov2d(vp, p_view, scale, quat, cov2d);
+        cov_to_conic(cov2d, conic);
+        project_pix(vp, p_view, xy);
+
+        // SH -> colour, evaluated with the WGSL expression tree (project_visible.wgsl:51-147).
+        float dir[3];
+        view_dir(vp, mean, dir);
+        float Y[25];
+        sh_basis<25>(vp.sh_degree, dir, Y);
+        const float *sh = sh_coeffs + (size_t)g * ncoef * 3;
+        float rgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float col = Y[0] * sh[ch];
+            if (vp.sh_degree >= 1) {
+                const float inner = ((-dir[1]) * sh[1 * 3 + ch] + dir[2] * sh[2 * 3 + ch]) - dir[0] * sh[3 * 3 + ch];
+                col = col + 0.48860251190292f * inner;
+            }
+            if (vp.sh_degree >= 2) {
+                float acc = Y[4] * sh[4 * 3 + ch];
+                for (int k = 5; k < 9; k++) acc = acc + Y[k] * sh[k * 3 + ch];
+                col = col + acc;
+            }
+            if (vp.sh_degree >= 3) {
+                float acc = Y[9] * sh[9 * 3 + ch];
+                for (int k = 10; k < 16; k++) acc = acc + Y[k] * sh[k * 3 + ch];
+                col = col + acc;
+            }
+            if (vp.sh_degree >= 4) {
+                float acc = Y[16] * sh[16 * 3 + ch];
+                for (int k = 17; k < 25; k++) acc = acc + Y[k] * sh[k * 3 + ch];
+                col = col + acc;
+            }
+            rgb[ch] = col + 0.5f;
+        }
+
+        const uint32_t radius = radius_from_conic(conic);
+        uint32_t bb[4];
+        get_tile_bbox(xy, radius, vp.tile_bounds, bb);
+        const TileTest tt = make_tile_test(conic, opac);
+        uint32_t area = 0;
+        for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
+            for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
+                if (can_be_visible(tt, tx, ty, xy)) area++;
+
+        float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
+        p[0] = xy[0];
+        p[1] = xy[1];
+        p[2] = conic[0];
+        p[3] = conic[1];
+        p[4] = conic[2];
+        p[5] = rgb[0];
+        p[6] = rgb[1];
+        p[7] = rgb[2];
+        p[8] = opac;
+        tiles_hit[c] = area;
+    }
+}
+
+// ---- MapGaussiansToIntersect ---------------------------------------------------------------
+// map_gaussian_to_intersects.wgsl:10-48
+__global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, const float *__restrict__ projected,
+                                                             const uint32_t *__restrict__ cum_tiles_hit,
+                                                             const uint32_t *__restrict__ num_visible,
+                                                             uint32_t cap, uint32_t *__restrict__ tile_ids,
+                                                             uint32_t *__restrict__ gids) {
+    const uint32_t V = *num_visible;
+    for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < V; c += gridDim.x * kThreads) {
+        const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
+        const float xy[2] = {p[0], p[1]};
+        const float conic[3] = {p[2], p[3], p[4]};
+        const float opac = p[8];
+        const uint32_t radius = radius_from_conic(conic);
+        uint32_t bb[4];
+        get_tile_bbox(xy, radius, vp.tile_bounds, bb);
+        const TileTest tt = make_tile_test(conic, opac);
+        uint32_t isect = c > 0 ? cum_tiles_hit[c - 1] : 0u;
+        for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
+            for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
+                if (can_be_visible(tt, tx, ty, xy) && isect < cap) {
+                    tile_ids[isect] = tx + ty * vp.tile_bounds[0];
+                    gids[isect] = c;
+                    isect++;
+                }
+    }
+}
+
+// ---- GetTileBinEdges -----------------------------------------------------------------------
+// get_tile_bin_edges.wgsl:15-42
+__global__ __launch_bounds__(kThreads) void k_tile_bin_edges(const uint32_t *__restrict__ sorted_tile_ids,
+                                                             const uint32_t *__restrict__ num_intersections,
+                                                             uint32_t *__restrict__ tile_bins) {
+    const uint32_t I = *num_intersections;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < I; i += gridDim.x * kThreads) {
+        const uint32_t cur = sorted_tile_ids[i];
+        if (i == I - 1) tile_bins[cur * 2 + 1] = I;
+        if (i == 0) {
+            tile_bins[cur * 2 + 0] = 0;
+        } else {
+            const uint32_t prev = sorted_tile_ids[i - 1];
+            if (prev != cur) {
+                tile_bins[prev * 2 + 1] = i;
+                tile_bins[cur * 2 + 0] = i;
+            }
+        }
+    }
+}
+
+uint32_t stride_grid(uint32_t work_items) { return max(1u, min(ceil_div(work_items, kThreads), 2048u)); }
+
+}  // namespace
+
+hipError_t launch_init(const BrushUniforms &u, const BrushAux &aux, uint32_t num_tiles, hipStream_t s) {
+    hipLaunchKernelGGL(k_init, dim3(stride_grid(num_tiles * 2)), dim3(kThreads), 0, s, u, aux.uniforms_buffer,
+                       aux.num_intersections, aux.overflow, aux.tile_bins, num_tiles * 2);
+    return hipGetLastError();
+}
+
+size_t cull_block_count(uint32_t n) { return ceil_div(n ? n : 1, kThreads); }
+
+hipError_t launch_project_cull(const ViewParams &vp, const float *means, const float *log_scales,
+                               const float *quats, uint32_t *key_all, uint32_t *compact_from_global,
+                               uint32_t *block_counts, uint32_t *num_visible, uint32_t *uniforms_buffer,
+                               uint32_t *keys, uint32_t *gids, hipStream_t s) {
+    const uint32_t n = vp.total_splats;
+    const uint32_t blocks = (uint32_t)cull_block_count(n);
+    hipLaunchKernelGGL(k_project_cull, dim3(blocks), dim3(kThreads), 0, s, vp, means, log_scales, quats, key_all,
+                       compact_from_global, block_counts);
+    hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, s, block_counts, blocks, num_visible,
+                       uniforms_buffer);
+    hipLaunchKernelGGL(k_compact, dim3(blocks), dim3(kThreads), 0, s, n, key_all, block_counts, keys, gids);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_visible(const ViewParams &vp, const float *means, const float *log_scales,
+                                  const float *quats, const float *sh, const float *raw_opac,
+                                  const uint32_t *num_visible, uint32_t *global_from_compact,
+                                  uint32_t *compact_from_global, float *projected, uint32_t *tiles_hit,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(k_project_visible, dim3(stride_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, means,
+                       log_scales, quats, sh, raw_opac, num_visible, global_from_compact, compact_from_global,
+                       projected, tiles_hit);
+    return hipGetLastError();
+}
+
+hipError_t launch_map_intersects(const ViewParams &vp, const float *projected, const uint32_t *cum_tiles_hit,
+                                 const uint32_t *num_visible, uint32_t cap, uint32_t *tile_ids, uint32_t *gids,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL(k_map_intersects, dim3(stride_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, projected,
+                       cum_tiles_hit, num_visible, cap, tile_ids, gids);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_bin_edges(const uint32_t *sorted_tile_ids, const uint32_t *num_intersections,
+                                 uint32_t cap, uint32_t *tile_bins, hipStream_t s) {
+    hipLaunchKernelGGL(k_tile_bin_edges, dim3(stride_grid(cap)), dim3(kThreads), 0, s, sorted_tile_ids,
+                       num_intersections, tile_bins);
+    return hipGetLastError();
+}
+
+}  // namespace brush

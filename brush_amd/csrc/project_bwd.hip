@@ -1,0 +1,243 @@
+// project_bwd.hip — parameter VJPs: SH / opacity / xy gather + projection backward, fused.
+//
+// Replaces:
+//   GatherGrads       crates/brush-render/src/shaders/gather_grads.wgsl:165-232
+//   ProjectBackwards  crates/brush-render/src/shaders/project_backwards.wgsl:75-227
+//   and the nine zero-fills of crates/brush-render/src/render.rs:505-507,539-547,573-575.
+//
+// One launch over GLOBAL splat ids.  Lane g looks up its compact id through the inverse map
+// the forward produced; visible splats gather their 9 compact-order gradients (36 B) and
+// compute the six dense outputs, non-visible splats store zeros.  Every dense gradient element
+// is therefore written exactly once, in global order, with no separate memset and no scatter.
+// Traffic per splat: 4 B (map) + 40 B params + 36 B compact grads (visible only) read,
+// 52 + 12*C B written.  Roofline: HBM.
+//
+// Compiled with -ffp-contract=off (same expression trees as the forward projection).
+#include "internal.hpp"
+#include "splat_math.hpp"
+
+#pragma clang fp contract(off)
+
+namespace brush {
+namespace {
+
+constexpr uint32_t kThreads = 256;
+
+// project_backwards.wgsl:25-57; G(a,b) = WGSL v_R[a][b] = column a, row b.
+__device__ __forceinline__ void quat_to_rotmat_vjp(const float q[4], const Mat3 &vR, float o[4]) {
+#define G(a, b) (vR.m[b][a])
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    o[0] = 2.0f * ((x * (G(1, 2) - G(2, 1)) + y * (G(2, 0) - G(0, 2))) + z * (G(0, 1) - G(1, 0)));
+    o[1] = 2.0f * (((-2.0f * x * (G(1, 1) + G(2, 2)) + y * (G(0, 1) + G(1, 0))) + z * (G(0, 2) + G(2, 0))) +
+                   w * (G(1, 2) - G(2, 1)));
+    o[2] = 2.0f * (((x * (G(0, 1) + G(1, 0)) - 2.0f * y * (G(0, 0) + G(2, 2))) + z * (G(1, 2) + G(2, 1))) +
+                   w * (G(2, 0) - G(0, 2)));
+    o[3] = 2.0f * (((x * (G(0, 2) + G(2, 0)) + y * (G(1, 2) + G(2, 1))) - 2.0f * z * (G(0, 0) + G(1, 1))) +
+                   w * (G(0, 1) - G(1, 0)));
+#undef G
+}
+
+// project_backwards.wgsl:59-72
+__device__ __forceinline__ void cov2d_to_conic_vjp(const float conic[3], const float v_conic[3], float o[3]) {
+    const float X[2][2] = {{conic[0], conic[1]}, {conic[1], conic[2]}};
+    const float Gm[2][2] = {{v_conic[0], v_conic[1] / 2.0f}, {v_conic[1] / 2.0f, v_conic[2]}};
+    float XG[2][2], S[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) XG[i][j] = X[i][0] * Gm[0][j] + X[i][1] * Gm[1][j];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) S[i][j] = XG[i][0] * X[0][j] + XG[i][1] * X[1][j];
+    o[0] = -S[0][0];
+    o[1] = -(S[0][1] + S[1][0]);
+    o[2] = -S[1][1];
+}
+
+__global__ __launch_bounds__(kThreads) void k_zero_compact_grads(const uint32_t *__restrict__ num_visible,
+                                                                 uint32_t n, float *__restrict__ v_xy_local,
+                                                                 float *__restrict__ v_conics,
+                                                                 float *__restrict__ v_colors) {
+    const uint32_t V = min(*num_visible, n);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t i = gtid; i < V * 2; i += stride) v_xy_local[i] = 0.0f;
+    for (uint32_t i = gtid; i < V * 3; i += stride) v_conics[i] = 0.0f;
+    for (uint32_t i = gtid; i < V * 4; i += stride) v_colors[i] = 0.0f;
+}
+
+template <int DEG>
+__global__ __launch_bounds__(kThreads) void k_project_backward(
+    ViewParams vp, const float *__restrict__ means, const float *__restrict__ log_scales,
+    const float *__restrict__ quats, const float *__restrict__ raw_opac,
+    const uint32_t *__restrict__ compact_from_global, const float *__restrict__ v_xy_local,
+    const float *__restrict__ v_conics, const float *__restrict__ v_colors, float *__restrict__ v_means,
+    float *__restrict__ v_xy, float *__restrict__ v_scales, float *__restrict__ v_quats,
+    float *__restrict__ v_sh, float *__restrict__ v_opac) {
+    const uint32_t g = blockIdx.x * kThreads + threadIdx.x;
+    if (g >= vp.total_splats) return;
+    constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
+    const uint32_t c = compact_from_global[g];
+
+    float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_quat[4] = {0.f, 0.f, 0.f, 0.f};
+    float o_xy[2] = {0.f, 0.f}, o_opac = 0.f;
+    float vcol[3] = {0.f, 0.f, 0.f};
+    float Y[ncoef];
+#pragma unroll
+    for (uint32_t k = 0; k < ncoef; k++) Y[k] = 0.f;
+
+    if (c != kInvalid) {
+        const float vxy[2] = {v_xy_local[(size_t)c * 2], v_xy_local[(size_t)c * 2 + 1]};
+        const float vconic[3] = {v_conics[(size_t)c * 3], v_conics[(size_t)c * 3 + 1], v_conics[(size_t)c * 3 + 2]};
+        const float4 vc4 = reinterpret_cast<const float4 *>(v_colors)[c];
+        vcol[0] = vc4.x;
+        vcol[1] = vc4.y;
+        vcol[2] = vc4.z;
+
+        const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
+        const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
+                                det_expf(log_scales[(size_t)g * 3 + 2])};
+        const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
+        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+
+        // ---- GatherGrads (gather_grads.wgsl:174-231)
+        float dir[3];
+        view_dir(vp, mean, dir);
+        sh_basis<ncoef>(DEG, dir, Y);
+        const float sg = det_sigmoid(raw_opac[g]);
+        o_opac = vc4.w * (sg * (1.0f - sg));
+        o_xy[0] = vxy[0];
+        o_xy[1] = vxy[1];
+
+        // ---- ProjectBackwards (project_backwards.wgsl:83-226)
+        const Mat3 W = view_rot(vp);
+        float p_view[3];
+        to_view(vp, mean, p_view);
+        float vpj[3];
+        {  // project_pix_vjp :19-23
+            const float rw = 1.0f / (p_view[2] + 1e-6f);
+            const float vp0 = vp.focal[0] * vxy[0], vp1 = vp.focal[1] * vxy[1];
+            vpj[0] = vp0 * rw;
+            vpj[1] = vp1 * rw;
+            vpj[2] = -(vp0 * p_view[0] + vp1 * p_view[1]) * rw * rw;
+        }
+        float vm[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) vm[i] = W.m[0][i] * vpj[0] + W.m[1][i] * vpj[1] + W.m[2][i] * vpj[2];
+
+        float cov2d[3], conic[3], v_cov2d[3];
+        calc_cov2d(vp, p_view, scale, quat, cov2d);
+        cov_to_conic(cov2d, conic);
+        cov2d_to_conic_vjp(conic, vconic, v_cov2d);
+
+        const float rz = 1.0f / p_view[2];
+        const float rz2 = rz * rz;
+        // J from the UNCLAMPED p_view (project_backwards.wgsl:134-138)
+        Mat3 J;
+        J.m[0][0] = vp.focal[0] * rz; J.m[0][1] = 0.0f; J.m[0][2] = (-vp.focal[0]) * p_view[0] * rz2;
+        J.m[1][0] = 0.0f; J.m[1][1] = vp.focal[1] * rz; J.m[1][2] = (-vp.focal[1]) * p_view[1] * rz2;
+        J.m[2][0] = 0.0f; J.m[2][1] = 0.0f; J.m[2][2] = 0.0f;
+        const Mat3 R = quat_to_rotmat(quat);
+        Mat3 S;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) S.m[i][j] = (i == j) ? scale[i] : 0.0f;
+        const Mat3 M = mul(R, S);
+        const Mat3 V = mul(M, transpose(M));
+        Mat3 v_cov;
+        v_cov.m[0][0] = v_cov2d[0]; v_cov.m[0][1] = 0.5f * v_cov2d[1]; v_cov.m[0][2] = 0.0f;
+        v_cov.m[1][0] = 0.5f * v_cov2d[1]; v_cov.m[1][1] = v_cov2d[2]; v_cov.m[1][2] = 0.0f;
+        v_cov.m[2][0] = 0.0f; v_cov.m[2][1] = 0.0f; v_cov.m[2][2] = 0.0f;
+        const Mat3 T = mul(J, W);
+        const Mat3 Tt = transpose(T);
+        const Mat3 Vt = transpose(V);
+        const Mat3 v_V = mul(mul(Tt, v_cov), T);
+        const Mat3 v_T = add(mul(mul(v_cov, T), Vt), mul(mul(transpose(v_cov), T), V));
+
+        const float c0 = v_V.m[0][0];
+        const float c1 = v_V.m[1][0] + v_V.m[0][1];
+        const float c2 = v_V.m[2][0] + v_V.m[0][2];
+        const float c3 = v_V.m[1][1];
+        const float c4 = v_V.m[2][1] + v_V.m[1][2];
+        const float c5 = v_V.m[2][2];
+
+        const Mat3 v_J = mul(v_T, transpose(W));
+        const float rz3 = rz2 * rz;
+        const float vJ02 = v_J.m[0][2], vJ12 = v_J.m[1][2], vJ00 = v_J.m[0][0], vJ11 = v_J.m[1][1];
+        float v_t[3];
+        v_t[0] = (-vp.focal[0]) * rz2 * vJ02;
+        v_t[1] = (-vp.focal[1]) * rz2 * vJ12;
+        v_t[2] = (((-vp.focal[0]) * rz2 * vJ00 + 2.0f * vp.focal[0] * p_view[0] * rz3 * vJ02) -
+                  vp.focal[1] * rz2 * vJ11) +
+                 2.0f * vp.focal[1] * p_view[1] * rz3 * vJ12;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            o_mean[i] = vm[i] + ((v_t[0] * W.m[0][i] + v_t[1] * W.m[1][i]) + v_t[2] * W.m[2][i]);
+
+        Mat3 two_vVs;
+        two_vVs.m[0][0] = 2.0f * c0; two_vVs.m[0][1] = 2.0f * (0.5f * c1); two_vVs.m[0][2] = 2.0f * (0.5f * c2);
+        two_vVs.m[1][0] = 2.0f * (0.5f * c1); two_vVs.m[1][1] = 2.0f * c3; two_vVs.m[1][2] = 2.0f * (0.5f * c4);
+        two_vVs.m[2][0] = 2.0f * (0.5f * c2); two_vVs.m[2][1] = 2.0f * (0.5f * c4); two_vVs.m[2][2] = 2.0f * c5;
+        const Mat3 v_M = mul(two_vVs, M);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float vs = (R.m[0][j] * v_M.m[0][j] + R.m[1][j] * v_M.m[1][j]) + R.m[2][j] * v_M.m[2][j];
+            o_scale[j] = vs * scale[j];  // log-space (:219)
+        }
+        const Mat3 v_R = mul(v_M, S);
+        quat_to_rotmat_vjp(quat, v_R, o_quat);
+    }
+
+    v_means[(size_t)g * 3 + 0] = o_mean[0];
+    v_means[(size_t)g * 3 + 1] = o_mean[1];
+    v_means[(size_t)g * 3 + 2] = o_mean[2];
+    v_scales[(size_t)g * 3 + 0] = o_scale[0];
+    v_scales[(size_t)g * 3 + 1] = o_scale[1];
+    v_scales[(size_t)g * 3 + 2] = o_scale[2];
+    reinterpret_cast<float4 *>(v_quats)[g] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
+    reinterpret_cast<float2 *>(v_xy)[g] = make_float2(o_xy[0], o_xy[1]);
+    v_opac[g] = o_opac;
+    float *vs = v_sh + (size_t)g * ncoef * 3;
+#pragma unroll
+    for (uint32_t k = 0; k < ncoef; k++) {
+        vs[k * 3 + 0] = Y[k] * vcol[0];
+        vs[k * 3 + 1] = Y[k] * vcol[1];
+        vs[k * 3 + 2] = Y[k] * vcol[2];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_zero_compact_grads(const uint32_t *num_visible, uint32_t n, float *v_xy_local, float *v_conics,
+                                     float *v_colors, hipStream_t s) {
+    const uint32_t grid = max(1u, min(ceil_div(n * 4u, kThreads), 1024u));
+    hipLaunchKernelGGL(k_zero_compact_grads, dim3(grid), dim3(kThreads), 0, s, num_visible, n, v_xy_local,
+                       v_conics, v_colors);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_backward(const ViewParams &vp, const float *means, const float *log_scales,
+                                   const float *quats, const float *raw_opac,
+                                   const uint32_t *compact_from_global, const float *v_xy_local,
+                                   const float *v_conics, const float *v_colors, float *v_means, float *v_xy,
+                                   float *v_scales, float *v_quats, float *v_sh, float *v_opac, hipStream_t s) {
+    if (vp.total_splats == 0) return hipSuccess;
+    const dim3 grid(ceil_div(vp.total_splats, kThreads)), block(kThreads);
+#define BRUSH_LAUNCH_PB(D)                                                                                   \
+    hipLaunchKernelGGL(k_project_backward<D>, grid, block, 0, s, vp, means, log_scales, quats, raw_opac,     \
+                       compact_from_global, v_xy_local, v_conics, v_colors, v_means, v_xy, v_scales, v_quats, \
+                       v_sh, v_opac)
+    switch (vp.sh_degree) {
+        case 0: BRUSH_LAUNCH_PB(0); break;
+        case 1: BRUSH_LAUNCH_PB(1); break;
+        case 2: BRUSH_LAUNCH_PB(2); break;
+        case 3: BRUSH_LAUNCH_PB(3); break;
+        default: BRUSH_LAUNCH_PB(4); break;
+    }
+#undef BRUSH_LAUNCH_PB
+    return hipGetLastError();
+}
+
+}  // namespace brush

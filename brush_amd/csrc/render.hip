@@ -1,0 +1,302 @@
+// render.hip — host orchestration of the forward and backward passes behind the C ABI.
+//
+// Replaces render_forward (crates/brush-render/src/render.rs:55-323) and
+// RenderBackwards::backward (render.rs:465-626).  Like the reference it only enqueues work on
+// the caller's stream and never reads a count back to the host; unlike the reference it
+// performs no allocation (the caller passes one workspace) and needs no indirect-dispatch
+// helper kernels (kernels read the device-side counts and grid-stride).
+#include <string.h>
+
+#include "internal.hpp"
+#include "splat_math.hpp"
+
+namespace brush {
+
+static thread_local int g_last_hip_error = 0;
+void set_last_hip_error(int e) { g_last_hip_error = e; }
+
+}  // namespace brush
+
+// Opt-in stage timing: events [0] = forward start, [1 + stage] = end of forward stage,
+// [kBwdStart] = backward start, then one per backward stage.
+struct BrushProfiler {
+    static constexpr int kFwdStages = BRUSH_STAGE_RASTERIZE + 1;
+    static constexpr int kBwdStages = BRUSH_NUM_STAGES - kFwdStages;
+    hipEvent_t fwd[kFwdStages + 1];
+    hipEvent_t bwd[kBwdStages + 1];
+    bool fwd_recorded = false, bwd_recorded = false;
+};
+
+namespace brush {
+static thread_local BrushProfiler *g_prof = nullptr;
+
+static inline void mark_fwd(hipStream_t s, int idx) {
+    if (g_prof) {
+        (void)hipEventRecord(g_prof->fwd[idx], s);
+        if (idx == BrushProfiler::kFwdStages) g_prof->fwd_recorded = true;
+    }
+}
+static inline void mark_bwd(hipStream_t s, int idx) {
+    if (g_prof) {
+        (void)hipEventRecord(g_prof->bwd[idx], s);
+        if (idx == BrushProfiler::kBwdStages) g_prof->bwd_recorded = true;
+    }
+}
+
+namespace {
+
+struct FwdWs {
+    uint32_t *key_all;       // [N] depth bits or 0xFFFFFFFF
+    uint32_t *block_counts;  // [ceil(N/256)]
+    uint32_t *pre_keys;      // [N] compacted, unsorted
+    uint32_t *pre_gids;      // [N]
+    uint32_t *sorted_keys;   // [N]
+    uint32_t *tiles_hit;     // [N]
+    uint32_t *tile_unsorted; // [cap]
+    uint32_t *gid_unsorted;  // [cap]
+    uint32_t *tile_sorted;   // [cap]
+    void *scan_ws;
+    void *sort_ws;           // sized for max(N, cap)
+    size_t bytes;
+};
+
+FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap) {
+    FwdWs f;
+    Carver c(ws);
+    const size_t nn = n ? n : 1, cc = cap ? cap : 1;
+    f.key_all = c.take<uint32_t>(nn);
+    f.block_counts = c.take<uint32_t>(cull_block_count(n));
+    f.pre_keys = c.take<uint32_t>(nn);
+    f.pre_gids = c.take<uint32_t>(nn);
+    f.sorted_keys = c.take<uint32_t>(nn);
+    f.tiles_hit = c.take<uint32_t>(nn);
+    f.tile_unsorted = c.take<uint32_t>(cc);
+    f.gid_unsorted = c.take<uint32_t>(cc);
+    f.tile_sorted = c.take<uint32_t>(cc);
+    f.scan_ws = c.take<char>(scan_workspace_bytes(n));
+    f.sort_ws = c.take<char>(sort_workspace_bytes(n > cap ? n : cap));
+    f.bytes = c.bytes();
+    return f;
+}
+
+struct BwdWs {
+    float *v_xy_local;  // [N,2] compact order
+    float *v_conics;    // [N,3]
+    float *v_colors;    // [N,4]
+    size_t bytes;
+};
+
+BwdWs carve_bwd(void *ws, uint32_t n) {
+    BwdWs b;
+    Carver c(ws);
+    const size_t nn = n ? n : 1;
+    b.v_xy_local = c.take<float>(nn * 2);
+    b.v_conics = c.take<float>(nn * 3);
+    b.v_colors = c.take<float>(nn * 4);
+    b.bytes = c.bytes();
+    return b;
+}
+
+bool aux_ok(const BrushAux *a, bool need_final_index) {
+    return a && a->projected_splats && a->uniforms_buffer && a->num_intersections && a->num_visible &&
+           (a->final_index || !need_final_index) && a->cum_tiles_hit && a->tile_bins &&
+           a->compact_gid_from_isect && a->global_from_compact_gid && a->compact_from_global_gid && a->overflow;
+}
+
+bool uniforms_ok(const BrushUniforms *u) {
+    if (!u || u->sh_degree > 4) return false;  // render.rs:44-52
+    if (u->tile_bounds[0] != ceil_div(u->img_size[0], kTileWidth) ||
+        u->tile_bounds[1] != ceil_div(u->img_size[1], kTileWidth))
+        return false;  // render.rs:82-85
+    return true;
+}
+
+}  // namespace
+}  // namespace brush
+
+using namespace brush;
+
+extern "C" const char *brush_version(void) { return "brush_amd 0.1.0 (gfx950)"; }
+
+extern "C" const char *brush_status_string(int status) {
+    switch (status) {
+        case BRUSH_OK: return "ok";
+        case BRUSH_ERR_INVALID_ARG: return "invalid argument";
+        case BRUSH_ERR_WORKSPACE_SMALL: return "workspace too small";
+        case BRUSH_ERR_HIP: return "HIP runtime error";
+        case BRUSH_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int brush_last_hip_error(void) { return g_last_hip_error; }
+
+extern "C" uint32_t brush_default_max_intersects(uint32_t n, uint32_t w, uint32_t h) {
+    const uint64_t tiles = (uint64_t)ceil_div(w, kTileWidth) * ceil_div(h, kTileWidth);
+    uint64_t m = (uint64_t)n * tiles;  // render.rs:204-206 (saturating_mul)
+    if (m > 128ull * 65535ull) m = 128ull * 65535ull;
+    return m ? (uint32_t)m : 1u;
+}
+
+extern "C" int brush_fwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
+                                        uint32_t max_intersects, size_t *bytes) {
+    (void)w;
+    (void)h;
+    if (!bytes || sh_degree > 4) return BRUSH_ERR_INVALID_ARG;
+    *bytes = carve_fwd(nullptr, n, max_intersects).bytes;
+    return BRUSH_OK;
+}
+
+extern "C" int brush_bwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree, size_t *bytes) {
+    (void)w;
+    (void)h;
+    if (!bytes || sh_degree > 4) return BRUSH_ERR_INVALID_ARG;
+    *bytes = carve_bwd(nullptr, n).bytes;
+    return BRUSH_OK;
+}
+
+extern "C" int brush_render_forward(const BrushUniforms *h_uniforms, const float *means, const float *log_scales,
+                                    const float *quats, const float *sh_coeffs, const float *raw_opacity,
+                                    uint32_t n, int raster_u32, void *out_img, const BrushAux *h_aux,
+                                    void *workspace, size_t workspace_bytes, brush_stream_t stream) {
+    if (!uniforms_ok(h_uniforms) || !aux_ok(h_aux, !raster_u32) || !out_img || !workspace)
+        return BRUSH_ERR_INVALID_ARG;
+    if (n > 0 && (!means || !log_scales || !quats || !sh_coeffs || !raw_opacity)) return BRUSH_ERR_INVALID_ARG;
+    const BrushAux &aux = *h_aux;
+    const uint32_t cap = aux.max_intersects;
+    if (cap == 0) return BRUSH_ERR_INVALID_ARG;
+    const FwdWs ws = carve_fwd(workspace, n, cap);
+    if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    BrushUniforms u = *h_uniforms;
+    u.num_visible = 0;
+    u.total_splats = n;
+    u.padding = 0;
+    const ViewParams vp = make_view_params(u, n);
+    const uint32_t w = u.img_size[0], h = u.img_size[1];
+    const uint32_t tbx = u.tile_bounds[0], tby = u.tile_bounds[1];
+    const uint32_t num_tiles = tbx * tby;
+
+    mark_fwd(s, 0);
+    // uniforms buffer, counters, tile_bins = 0
+    BRUSH_HIP_CHECK(launch_init(u, aux, num_tiles, s));
+    // ProjectSplats + order-preserving compaction (render.rs:123-142)
+    BRUSH_HIP_CHECK(launch_project_cull(vp, means, log_scales, quats, ws.key_all, aux.compact_from_global_gid,
+                                        ws.block_counts, aux.num_visible, aux.uniforms_buffer, ws.pre_keys,
+                                        ws.pre_gids, s));
+    mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_CULL);
+    // DepthSort: keys = f32 depth bits, all 32 bits (render.rs:151-156)
+    BRUSH_HIP_CHECK(sort_launch(ws.pre_keys, ws.pre_gids, ws.sorted_keys, aux.global_from_compact_gid,
+                                aux.num_visible, n, 32, ws.sort_ws, s));
+    mark_fwd(s, 1 + BRUSH_STAGE_DEPTH_SORT);
+    // ProjectVisible (render.rs:161-184)
+    BRUSH_HIP_CHECK(launch_project_visible(vp, means, log_scales, quats, sh_coeffs, raw_opacity, aux.num_visible,
+                                           aux.global_from_compact_gid, aux.compact_from_global_gid,
+                                           aux.projected_splats, ws.tiles_hit, s));
+    mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_VISIBLE);
+    // PrefixSum over all N, tail treated as 0 (render.rs:186-192); total -> num_intersections
+    BRUSH_HIP_CHECK(scan_launch(ws.tiles_hit, aux.cum_tiles_hit, n, aux.num_visible, aux.num_intersections, cap,
+                                aux.overflow, ws.scan_ws, s));
+    mark_fwd(s, 1 + BRUSH_STAGE_PREFIX_SUM);
+    // MapGaussiansToIntersect (render.rs:211-223)
+    BRUSH_HIP_CHECK(launch_map_intersects(vp, aux.projected_splats, aux.cum_tiles_hit, aux.num_visible, cap,
+                                          ws.tile_unsorted, ws.gid_unsorted, s));
+    mark_fwd(s, 1 + BRUSH_STAGE_MAP_INTERSECTS);
+    // Tile sort on bits = 32 - clz(num_tiles) (render.rs:227-237)
+    uint32_t bits = 0;
+    while (bits < 32 && (num_tiles >> bits) != 0) bits++;
+    BRUSH_HIP_CHECK(sort_launch(ws.tile_unsorted, ws.gid_unsorted, ws.tile_sorted, aux.compact_gid_from_isect,
+                                aux.num_intersections, cap, bits, ws.sort_ws, s));
+    mark_fwd(s, 1 + BRUSH_STAGE_TILE_SORT);
+    // GetTileBinEdges (render.rs:239-262)
+    BRUSH_HIP_CHECK(launch_tile_bin_edges(ws.tile_sorted, aux.num_intersections, cap, aux.tile_bins, s));
+    mark_fwd(s, 1 + BRUSH_STAGE_TILE_BINS);
+    // Rasterize (render.rs:267-307)
+    BRUSH_HIP_CHECK(launch_rasterize(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
+                                     aux.projected_splats, raster_u32, out_img, aux.final_index, s));
+    mark_fwd(s, 1 + BRUSH_STAGE_RASTERIZE);
+    return BRUSH_OK;
+}
+
+extern "C" int brush_render_backward(const BrushUniforms *h_uniforms, const BrushAux *h_aux, const float *means,
+                                     const float *log_scales, const float *quats, const float *raw_opacity,
+                                     uint32_t n, const float *out_img, const float *v_out, float *v_means,
+                                     float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
+                                     void *workspace, size_t workspace_bytes, brush_stream_t stream) {
+    if (!uniforms_ok(h_uniforms) || !aux_ok(h_aux, true) || !out_img || !v_out || !workspace)
+        return BRUSH_ERR_INVALID_ARG;
+    if (n > 0 && (!means || !log_scales || !quats || !raw_opacity || !v_means || !v_xy || !v_scales || !v_quats ||
+                  !v_sh || !v_opac))
+        return BRUSH_ERR_INVALID_ARG;
+    const BrushAux &aux = *h_aux;
+    const BwdWs ws = carve_bwd(workspace, n);
+    if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    BrushUniforms u = *h_uniforms;
+    u.total_splats = n;
+    const ViewParams vp = make_view_params(u, n);
+    const uint32_t w = u.img_size[0], h = u.img_size[1];
+    const uint32_t tbx = u.tile_bounds[0], tby = u.tile_bounds[1];
+
+    mark_bwd(s, 0);
+    // compact-order accumulators are atomically added to: zero the first V rows (render.rs:505-507)
+    BRUSH_HIP_CHECK(launch_zero_compact_grads(aux.num_visible, n, ws.v_xy_local, ws.v_conics, ws.v_colors, s));
+    mark_bwd(s, 1);
+    // RasterizeBackwards (render.rs:515-532)
+    BRUSH_HIP_CHECK(launch_rasterize_backward(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
+                                              aux.projected_splats, aux.final_index, out_img, v_out,
+                                              ws.v_xy_local, ws.v_conics, ws.v_colors, s));
+    mark_bwd(s, 2);
+    // GatherGrads + ProjectBackwards fused, dense outputs written once (render.rs:534-594)
+    BRUSH_HIP_CHECK(launch_project_backward(vp, means, log_scales, quats, raw_opacity, aux.compact_from_global_gid,
+                                            ws.v_xy_local, ws.v_conics, ws.v_colors, v_means, v_xy, v_scales,
+                                            v_quats, v_sh, v_opac, s));
+    mark_bwd(s, 3);
+    return BRUSH_OK;
+}
+
+// ---- opt-in stage timing ------------------------------------------------------------------
+
+extern "C" int brush_profiler_create(BrushProfiler **out) {
+    if (!out) return BRUSH_ERR_INVALID_ARG;
+    BrushProfiler *p = new BrushProfiler();
+    for (auto &e : p->fwd) BRUSH_HIP_CHECK(hipEventCreate(&e));
+    for (auto &e : p->bwd) BRUSH_HIP_CHECK(hipEventCreate(&e));
+    *out = p;
+    return BRUSH_OK;
+}
+
+extern "C" void brush_profiler_destroy(BrushProfiler *p) {
+    if (!p) return;
+    if (g_prof == p) g_prof = nullptr;
+    for (auto &e : p->fwd) (void)hipEventDestroy(e);
+    for (auto &e : p->bwd) (void)hipEventDestroy(e);
+    delete p;
+}
+
+extern "C" void brush_profiler_attach(BrushProfiler *p) { g_prof = p; }
+
+extern "C" int brush_profiler_read(BrushProfiler *p, float *h_ms) {
+    if (!p || !h_ms) return BRUSH_ERR_INVALID_ARG;
+    for (int i = 0; i < BRUSH_NUM_STAGES; i++) h_ms[i] = 0.0f;
+    if (p->fwd_recorded) {
+        BRUSH_HIP_CHECK(hipEventSynchronize(p->fwd[BrushProfiler::kFwdStages]));
+        for (int i = 0; i < BrushProfiler::kFwdStages; i++)
+            BRUSH_HIP_CHECK(hipEventElapsedTime(&h_ms[i], p->fwd[i], p->fwd[i + 1]));
+    }
+    if (p->bwd_recorded) {
+        BRUSH_HIP_CHECK(hipEventSynchronize(p->bwd[BrushProfiler::kBwdStages]));
+        for (int i = 0; i < BrushProfiler::kBwdStages; i++)
+            BRUSH_HIP_CHECK(hipEventElapsedTime(&h_ms[BrushProfiler::kFwdStages + i], p->bwd[i], p->bwd[i + 1]));
+    }
+    return BRUSH_OK;
+}
+
+extern "C" const char *brush_stage_name(int stage) {
+    static const char *names[BRUSH_NUM_STAGES] = {"project_cull", "depth_sort", "project_visible", "prefix_sum",
+                                                  "map_intersects", "tile_sort", "tile_bins", "rasterize",
+                                                  "bwd_zero", "rasterize_bwd", "project_bwd"};
+    return (stage >= 0 && stage < BRUSH_NUM_STAGES) ? names[stage] : "?";
+}

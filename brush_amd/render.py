@@ -1,0 +1,272 @@
+"""render_splats — host mirror of brush-render's op surface over the HIP C ABI.
+
+Reference interface (paths relative to the reference checkout):
+  trait Backend::render_splats         crates/brush-render/src/lib.rs:66-86
+  struct RenderAux                     crates/brush-render/src/lib.rs:20-63
+  impl Backend for Autodiff<..>        crates/brush-render/src/render.rs:366-463
+  impl Backward<_,6> for RenderBackwards  render.rs:465-626
+
+PyTorch is plumbing here: device memory, the current stream and autograd bookkeeping.  Every
+kernel is in libbrush_hip.so; there is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .camera import Camera
+
+# When True every buffer the op allocates is filled with 0xCD bytes first, the counterpart of
+# the reference's -12345 poison under cfg(test) (crates/brush-kernel/src/lib.rs:134-147).
+DEBUG_POISON = False
+
+
+def sh_coeffs_for_degree(degree: int) -> int:
+    """render.rs:40-42"""
+    return (degree + 1) ** 2
+
+
+def sh_degree_from_coeffs(coeffs_per_channel: int) -> int:
+    """render.rs:44-53 (panics on an invalid count)."""
+    table = {1: 0, 4: 1, 9: 2, 16: 3, 25: 4}
+    if coeffs_per_channel not in table:
+        raise ValueError(f"Invalid nr. of sh bases {coeffs_per_channel}")
+    return table[coeffs_per_channel]
+
+
+def _empty(shape, dtype, device):
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if DEBUG_POISON and t.numel() > 0:
+        t.view(torch.uint8).fill_(0xCD)
+    return t
+
+
+@dataclass
+class RenderAux:
+    """Mirror of RenderAux (lib.rs:20-33); integer tensors are int32 like Burn's."""
+    projected_splats: torch.Tensor         # [N,9] f32, first num_visible rows valid
+    uniforms_buffer: torch.Tensor          # [28] i32
+    num_intersections: torch.Tensor        # [1] i32
+    num_visible: torch.Tensor              # [1] i32
+    final_index: torch.Tensor              # [h,w] i32
+    cum_tiles_hit: torch.Tensor            # [N] i32
+    tile_bins: torch.Tensor                # [ty,tx,2] i32
+    compact_gid_from_isect: torch.Tensor   # [max_intersects] i32
+    global_from_compact_gid: torch.Tensor  # [N] i32
+    # build extensions
+    compact_from_global_gid: torch.Tensor  # [N] i32 (-1 = not visible)
+    overflow: torch.Tensor                 # [1] i32, 1 if intersections were truncated
+    max_intersects: int = 0
+
+    def read_num_visible(self) -> int:
+        """lib.rs:42-47 (a host readback; not on the hot path)."""
+        return int(self.num_visible.item())
+
+    def read_num_intersections(self) -> int:
+        """lib.rs:49-54"""
+        return int(self.num_intersections.item())
+
+    def read_tile_depth(self) -> torch.Tensor:
+        """lib.rs:56-62"""
+        return self.tile_bins[..., 1] - self.tile_bins[..., 0]
+
+    def _as_struct(self) -> _lib.BrushAux:
+        s = _lib.BrushAux()
+        for name in ("projected_splats", "uniforms_buffer", "num_intersections", "num_visible", "final_index",
+                     "cum_tiles_hit", "tile_bins", "compact_gid_from_isect", "global_from_compact_gid",
+                     "compact_from_global_gid", "overflow"):
+            setattr(s, name, getattr(self, name).data_ptr())
+        s.max_intersects = int(self.max_intersects)
+        return s
+
+
+def pack_uniforms(cam: Camera, img_size, sh_degree: int, total_splats: int) -> _lib.BrushUniforms:
+    """render.rs:82-116: tile bounds, viewmat (column-major), focal, centre."""
+    w, h = int(img_size[0]), int(img_size[1])
+    u = _lib.BrushUniforms()
+    w2l = cam.world_to_local()  # row-major [r][c]
+    u.viewmat[:] = [float(w2l[r][c]) for c in range(4) for r in range(4)]
+    f = cam.focal((w, h))
+    c = cam.center((w, h))
+    u.focal[:] = [float(f[0]), float(f[1])]
+    u.pixel_center[:] = [float(c[0]), float(c[1])]
+    u.img_size[:] = [w, h]
+    u.tile_bounds[:] = [-(-w // _lib.TILE_WIDTH), -(-h // _lib.TILE_WIDTH)]
+    u.sh_degree = int(sh_degree)
+    u.num_visible = 0
+    u.total_splats = int(total_splats)
+    u.padding = 0
+    return u
+
+
+def _check_inputs(means, xy_dummy, log_scales, quats, sh_coeffs, raw_opacity):
+    """DimCheck of render.rs:74-79 (assert on mismatch) plus dtype/device requirements."""
+    n = means.shape[0]
+    assert means.dim() == 2 and means.shape[1] == 3, f"means must be [D,3], got {tuple(means.shape)}"
+    assert log_scales.shape == (n, 3), f"log_scales must be [D,3], got {tuple(log_scales.shape)}"
+    assert quats.shape == (n, 4), f"quats must be [D,4], got {tuple(quats.shape)}"
+    assert sh_coeffs.dim() == 3 and sh_coeffs.shape[0] == n and sh_coeffs.shape[2] == 3, \
+        f"sh_coeffs must be [D,C,3], got {tuple(sh_coeffs.shape)}"
+    assert raw_opacity.shape == (n,), f"raw_opacity must be [D], got {tuple(raw_opacity.shape)}"
+    assert xy_dummy is None or xy_dummy.shape == (n, 2)
+    for t in (means, log_scales, quats, sh_coeffs, raw_opacity):
+        assert t.is_cuda, "brush_amd has no CPU path: tensors must live on the GPU"
+        assert t.dtype == torch.float32
+    return n
+
+
+def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, raw_opacity, render_u32: bool,
+                  max_intersects: Optional[int]):
+    l = _lib.lib()
+    n = means.shape[0]
+    w, h = int(img_size[0]), int(img_size[1])
+    dev = means.device
+    sh_degree = sh_degree_from_coeffs(sh_coeffs.shape[1])
+    u = pack_uniforms(cam, (w, h), sh_degree, n)
+    tbx, tby = int(u.tile_bounds[0]), int(u.tile_bounds[1])
+    cap = int(max_intersects) if max_intersects is not None else int(l.brush_default_max_intersects(n, w, h))
+    cap = max(cap, 1)
+    i32 = torch.int32
+    nn = max(n, 1)
+    aux = RenderAux(
+        projected_splats=_empty((nn, _lib.PROJECTED_FLOATS), torch.float32, dev),
+        uniforms_buffer=_empty((_lib.UNIFORM_WORDS,), i32, dev),
+        num_intersections=_empty((1,), i32, dev),
+        num_visible=_empty((1,), i32, dev),
+        final_index=_empty((h, w), i32, dev),
+        cum_tiles_hit=_empty((nn,), i32, dev),
+        tile_bins=_empty((tby, tbx, 2), i32, dev),
+        compact_gid_from_isect=_empty((cap,), i32, dev),
+        global_from_compact_gid=_empty((nn,), i32, dev),
+        compact_from_global_gid=_empty((nn,), i32, dev),
+        overflow=_empty((1,), i32, dev),
+        max_intersects=cap,
+    )
+    out = _empty((h, w, 1), i32, dev) if render_u32 else _empty((h, w, 4), torch.float32, dev)
+    nbytes = C.c_size_t()
+    _lib.check(l.brush_fwd_workspace_size(n, w, h, sh_degree, cap, C.byref(nbytes)), "brush_fwd_workspace_size")
+    ws = _empty((max(nbytes.value, 1),), torch.uint8, dev)
+    means, log_scales, quats = means.contiguous(), log_scales.contiguous(), quats.contiguous()
+    sh_coeffs, raw_opacity = sh_coeffs.contiguous(), raw_opacity.contiguous()
+    s = aux._as_struct()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(l.brush_render_forward(C.byref(u), means.data_ptr(), log_scales.data_ptr(), quats.data_ptr(),
+                                          sh_coeffs.data_ptr(), raw_opacity.data_ptr(), n, 1 if render_u32 else 0,
+                                          out.data_ptr(), C.byref(s), ws.data_ptr(), nbytes.value, stream),
+                   "brush_render_forward")
+    return out, aux, u
+
+
+def grad_block_layout(n: int, ncoef: int):
+    """Offsets (in floats) of [v_means | v_scales | v_quats | v_opac | v_sh | v_xy] in one block.
+
+    The first five are the parameter gradients that data-parallel training all-reduces as one
+    contiguous message; v_xy (densification statistic) sits at the tail.
+    """
+    sizes = [("v_means", n * 3), ("v_scales", n * 3), ("v_quats", n * 4), ("v_opac", n), ("v_sh", n * ncoef * 3),
+             ("v_xy", n * 2)]
+    off, layout = 0, {}
+    for name, sz in sizes:
+        layout[name] = (off, sz)
+        off += (sz + 3) // 4 * 4  # keep every segment 16-byte aligned
+    return layout, off
+
+
+def _backward_impl(u, aux: RenderAux, means, log_scales, quats, raw_opacity, ncoef, out_img, v_out,
+                   block: Optional[torch.Tensor] = None):
+    l = _lib.lib()
+    n = means.shape[0]
+    dev = means.device
+    w, h = int(u.img_size[0]), int(u.img_size[1])
+    layout, total = grad_block_layout(n, ncoef)
+    if block is None:
+        block = _empty((max(total, 1),), torch.float32, dev)
+    assert block.numel() >= total and block.dtype == torch.float32 and block.is_contiguous()
+
+    def seg(name, shape):
+        off, sz = layout[name]
+        return block[off:off + sz].view(shape)
+
+    g = {
+        "v_means": seg("v_means", (n, 3)), "v_scales": seg("v_scales", (n, 3)), "v_quats": seg("v_quats", (n, 4)),
+        "v_opac": seg("v_opac", (n,)), "v_sh": seg("v_sh", (n, ncoef, 3)), "v_xy": seg("v_xy", (n, 2)),
+    }
+    nbytes = C.c_size_t()
+    _lib.check(l.brush_bwd_workspace_size(n, w, h, int(u.sh_degree), C.byref(nbytes)), "brush_bwd_workspace_size")
+    ws = _empty((max(nbytes.value, 1),), torch.uint8, dev)
+    v_out = v_out.contiguous()
+    s = aux._as_struct()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(l.brush_render_backward(C.byref(u), C.byref(s), means.data_ptr(), log_scales.data_ptr(),
+                                           quats.data_ptr(), raw_opacity.data_ptr(), n, out_img.data_ptr(),
+                                           v_out.data_ptr(), g["v_means"].data_ptr(), g["v_xy"].data_ptr(),
+                                           g["v_scales"].data_ptr(), g["v_quats"].data_ptr(), g["v_sh"].data_ptr(),
+                                           g["v_opac"].data_ptr(), ws.data_ptr(), nbytes.value, stream),
+                   "brush_render_backward")
+    return g, block
+
+
+class _RenderSplatsFn(torch.autograd.Function):
+    """Parents in the order of render.rs:420-427: means, xy_dummy, log_scales, quats, sh, raw_opacity."""
+
+    @staticmethod
+    def forward(ctx, means, xy_dummy, log_scales, quats, sh_coeffs, raw_opacity, holder):
+        out, aux, u = _forward_impl(holder["cam"], holder["img_size"], means, log_scales, quats, sh_coeffs,
+                                    raw_opacity, False, holder["max_intersects"])
+        holder["aux"] = aux
+        ctx.u, ctx.aux, ctx.ncoef = u, aux, sh_coeffs.shape[1]
+        ctx.save_for_backward(means, log_scales, quats, raw_opacity, out)
+        ctx.mark_non_differentiable()
+        return out
+
+    @staticmethod
+    def backward(ctx, v_output):
+        means, log_scales, quats, raw_opacity, out = ctx.saved_tensors
+        g, _ = _backward_impl(ctx.u, ctx.aux, means, log_scales, quats, raw_opacity, ctx.ncoef, out,
+                              v_output.to(torch.float32))
+        return g["v_means"], g["v_xy"], g["v_scales"], g["v_quats"], g["v_sh"], g["v_opac"], None
+
+
+def render_splats(cam: Camera, img_size, means: torch.Tensor, xy_grad_dummy: Optional[torch.Tensor],
+                  log_scales: torch.Tensor, quats: torch.Tensor, sh_coeffs: torch.Tensor,
+                  raw_opacity: torch.Tensor, render_u32_buffer: bool = False,
+                  max_intersects: Optional[int] = None) -> Tuple[torch.Tensor, RenderAux]:
+    """Backend::render_splats (lib.rs:75-85).
+
+    Returns (img, aux): img is float32 [h,w,4] (rgb, 1-T; no background blend) or, with
+    `render_u32_buffer`, int32 [h,w,1] packed RGBA8.  `xy_grad_dummy` only carries the
+    screen-space xy gradient (global order, pixel units).  `max_intersects` defaults to the
+    reference's min(N*tiles, 128*65535); aux.overflow reports truncation.
+    """
+    _check_inputs(means, xy_grad_dummy, log_scales, quats, sh_coeffs, raw_opacity)
+    tracked = torch.is_grad_enabled() and not render_u32_buffer and any(
+        t is not None and t.requires_grad for t in (means, xy_grad_dummy, log_scales, quats, sh_coeffs, raw_opacity))
+    if not tracked:
+        # UnTracked branch (render.rs:453-460): plain forward, no state kept.
+        with torch.no_grad():
+            out, aux, _ = _forward_impl(cam, img_size, means, log_scales, quats, sh_coeffs, raw_opacity,
+                                        render_u32_buffer, max_intersects)
+        return out, aux
+    if xy_grad_dummy is None:
+        xy_grad_dummy = torch.zeros((means.shape[0], 2), dtype=torch.float32, device=means.device)
+    holder = {"cam": cam, "img_size": img_size, "max_intersects": max_intersects}
+    out = _RenderSplatsFn.apply(means, xy_grad_dummy, log_scales, quats, sh_coeffs, raw_opacity, holder)
+    return out, holder["aux"]
+
+
+def uniforms_to_numpy(aux: RenderAux) -> dict:
+    """Decode aux.uniforms_buffer (28 words) into typed fields (debug / test aid)."""
+    words = aux.uniforms_buffer.cpu().numpy().astype(np.int32).view(np.uint32)
+    f = words.view(np.float32)
+    return {
+        "viewmat": f[0:16].copy(), "focal": f[16:18].copy(), "img_size": words[18:20].copy(),
+        "tile_bounds": words[20:22].copy(), "pixel_center": f[22:24].copy(), "sh_degree": int(words[24]),
+        "num_visible": int(words[25]), "total_splats": int(words[26]),
+    }

@@ -1,0 +1,174 @@
+/*
+ * brush_hip.h — C ABI of libbrush_hip.so: the MI355X (gfx950) replacement for the
+ * splat-rasterizer hot path of wartron/brush.
+ *
+ * Drop-in boundary.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference checkout):
+ *
+ *   brush_render_forward    <- render_forward / Backend::render_splats
+ *                              crates/brush-render/src/render.rs:55-323, src/lib.rs:66-86
+ *   brush_render_backward   <- impl Backward<_,6> for RenderBackwards
+ *                              crates/brush-render/src/render.rs:465-626
+ *   brush_radix_argsort_u32 <- radix_argsort          crates/brush-sort/src/lib.rs:32-37
+ *   brush_inclusive_scan_u32<- prefix_sum             crates/brush-prefix-sum/src/lib.rs:17
+ *   *_workspace_size        <- create_tensor / client.empty scratch allocation
+ *                              crates/brush-kernel/src/lib.rs:125-150
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless its name starts with `h_`.
+ *   - The caller owns all memory (inputs, outputs, aux, workspace).  The library never
+ *     allocates, frees or synchronises on these paths; all work is enqueued on `stream`
+ *     (a hipStream_t) and the call returns immediately.  Data-dependent sizes
+ *     (num_visible, num_intersections) stay on the device.
+ *   - Functions are re-entrant: no global mutable state, per-call workspace.
+ *   - Return value: BRUSH_OK or a negative BrushStatus; nothing aborts.
+ *   - All floating point is f32, all indices/counts u32 (i32-typed tensors in Burn).
+ */
+#ifndef BRUSH_HIP_H
+#define BRUSH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *brush_stream_t; /* hipStream_t */
+
+typedef enum BrushStatus {
+    BRUSH_OK = 0,
+    BRUSH_ERR_INVALID_ARG = -1,    /* bad shape / null pointer / sh_degree > 4 / bits > 32 */
+    BRUSH_ERR_WORKSPACE_SMALL = -2,
+    BRUSH_ERR_HIP = -3,            /* a HIP call failed; see brush_last_hip_error() */
+    BRUSH_ERR_NO_DEVICE = -4
+} BrushStatus;
+
+/* RenderUniforms, 28 words — crates/brush-render/src/shaders/helpers.wgsl:7-30, filled like
+ * render.rs:102-116.  viewmat is world->camera, column-major.  num_visible is an OUTPUT of the
+ * forward pass inside aux.uniforms_buffer (word 25, render.rs:145-149); the host copy passed
+ * in is read-only and its num_visible/total_splats/padding fields are ignored. */
+typedef struct BrushUniforms {
+    float viewmat[16];
+    float focal[2];
+    uint32_t img_size[2]; /* (w, h) */
+    uint32_t tile_bounds[2];
+    float pixel_center[2];
+    uint32_t sh_degree;
+    uint32_t num_visible;
+    uint32_t total_splats;
+    uint32_t padding;
+} BrushUniforms;
+
+#define BRUSH_TILE_WIDTH 16u
+#define BRUSH_PROJECTED_FLOATS 9u /* ProjectedSplat, helpers.wgsl:33-43 */
+
+/* Device-pointer mirror of RenderAux (crates/brush-render/src/lib.rs:20-33).  All buffers are
+ * caller-allocated with the shapes below and must stay alive and unmodified between
+ * brush_render_forward and brush_render_backward (render.rs:436-446). */
+typedef struct BrushAux {
+    float *projected_splats;           /* [N,9] f32; rows < num_visible valid, compact order */
+    uint32_t *uniforms_buffer;         /* [28]  written by forward (num_visible at word 25) */
+    uint32_t *num_intersections;       /* [1]   = min(sum tiles hit, max_intersects) */
+    uint32_t *num_visible;             /* [1] */
+    uint32_t *final_index;             /* [h,w] last contributing isect id (0 if none) */
+    uint32_t *cum_tiles_hit;           /* [N]   inclusive scan of tiles hit; tail == total */
+    uint32_t *tile_bins;               /* [ty,tx,2] [start,end) into compact_gid_from_isect */
+    uint32_t *compact_gid_from_isect;  /* [max_intersects] sorted by (tile, depth) */
+    uint32_t *global_from_compact_gid; /* [N] depth order; entries >= num_visible are 0 */
+    uint32_t *compact_from_global_gid; /* [N] inverse of global_from_compact_gid, 0xFFFFFFFF for
+                                          non-visible splats (build extension: lets the backward
+                                          write each dense gradient exactly once) */
+    uint32_t *overflow;                /* [1] set to 1 when intersections were truncated at
+                                          max_intersects (the reference truncates silently,
+                                          map_gaussian_to_intersects.wgsl:40) */
+    uint32_t max_intersects;           /* capacity; reference: min(N*tiles, 128*65535)
+                                          (render.rs:204-206) */
+} BrushAux;
+
+/* ---- introspection ------------------------------------------------------------------ */
+const char *brush_version(void);
+const char *brush_status_string(int status);
+/* hipError_t of the last failing HIP call on this host thread (0 if none). */
+int brush_last_hip_error(void);
+/* Reference limit helper: min(N * tiles, 128*65535), at least 1 (render.rs:204-206). */
+uint32_t brush_default_max_intersects(uint32_t n, uint32_t w, uint32_t h);
+
+/* ---- radix argsort (brush-sort) ----------------------------------------------------- */
+/* Stable LSD argsort of the first *d_n (device scalar, <= max_n) key/value pairs on the low
+ * 4*ceil(bits/4) key bits (the reference runs ceil(bits/4) 4-bit passes,
+ * brush-sort/src/lib.rs:58).  Inputs are not modified; outputs hold the sorted pairs in
+ * [0, *d_n); elements beyond are unspecified (sort_scatter.wgsl:118-121). */
+int brush_radix_argsort_workspace_size(uint32_t max_n, size_t *bytes);
+int brush_radix_argsort_u32(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
+                            uint32_t *vals_out, const uint32_t *d_n, uint32_t max_n,
+                            uint32_t sorting_bits, void *workspace, size_t workspace_bytes,
+                            brush_stream_t stream);
+
+/* ---- prefix sum (brush-prefix-sum) ---------------------------------------------------- */
+/* out[i] = in[0] + ... + in[i] (wrapping u32), n known on the host like the reference's
+ * tensor shape (brush-prefix-sum/src/lib.rs:19). in == out is allowed. */
+int brush_inclusive_scan_workspace_size(uint32_t n, size_t *bytes);
+int brush_inclusive_scan_u32(const uint32_t *in, uint32_t *out, uint32_t n, void *workspace,
+                             size_t workspace_bytes, brush_stream_t stream);
+
+/* ---- render forward ------------------------------------------------------------------- */
+int brush_fwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
+                             uint32_t max_intersects, size_t *bytes);
+/* means[N,3] log_scales[N,3] quats[N,4] (w,x,y,z; already normalised) sh_coeffs[N,C,3]
+ * raw_opacity[N].  out_img: raster_u32 == 0 -> float[h,w,4] (rgb, 1-T); != 0 -> uint32[h,w]
+ * packed RGBA8 (rasterize.wgsl:106-109) and aux->final_index is not written. */
+int brush_render_forward(const BrushUniforms *h_uniforms, const float *means,
+                         const float *log_scales, const float *quats, const float *sh_coeffs,
+                         const float *raw_opacity, uint32_t n, int raster_u32, void *out_img,
+                         const BrushAux *h_aux, void *workspace, size_t workspace_bytes,
+                         brush_stream_t stream);
+
+/* ---- render backward ------------------------------------------------------------------ */
+int brush_bwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
+                             size_t *bytes);
+/* Gradients in the parent order of render.rs:420-427,598-624:
+ * v_means[N,3] v_xy[N,2] (global order, pixel units) v_scales[N,3] (log-space)
+ * v_quats[N,4] v_sh[N,C,3] v_opac[N] — dense, every element written, 0 for non-visible
+ * splats.  out_img / v_out are float[h,w,4]. */
+int brush_render_backward(const BrushUniforms *h_uniforms, const BrushAux *h_aux,
+                          const float *means, const float *log_scales, const float *quats,
+                          const float *raw_opacity, uint32_t n, const float *out_img,
+                          const float *v_out, float *v_means, float *v_xy, float *v_scales,
+                          float *v_quats, float *v_sh, float *v_opac, void *workspace,
+                          size_t workspace_bytes, brush_stream_t stream);
+
+/* ---- opt-in stage timing ---------------------------------------------------------------- */
+/* Counterpart of the reference's tracing spans + sync-span layer (render.rs:69-267,474-577;
+ * crates/sync-span/src/lib.rs:12-49): when a profiler is attached to the calling host thread,
+ * brush_render_forward / brush_render_backward record a hipEvent on `stream` after every
+ * stage.  Nothing is recorded (and no event exists) when no profiler is attached, so the
+ * default path stays free of events and synchronisation. */
+typedef struct BrushProfiler BrushProfiler;
+enum {
+    BRUSH_STAGE_PROJECT_CULL = 0, /* init + ProjectSplats + compaction          (fwd) */
+    BRUSH_STAGE_DEPTH_SORT,       /* radix argsort of depth keys                (fwd) */
+    BRUSH_STAGE_PROJECT_VISIBLE,  /* ProjectVisible                             (fwd) */
+    BRUSH_STAGE_PREFIX_SUM,       /* cum_tiles_hit                              (fwd) */
+    BRUSH_STAGE_MAP_INTERSECTS,   /* MapGaussiansToIntersect                    (fwd) */
+    BRUSH_STAGE_TILE_SORT,        /* radix argsort of tile ids                  (fwd) */
+    BRUSH_STAGE_TILE_BINS,        /* GetTileBinEdges                            (fwd) */
+    BRUSH_STAGE_RASTERIZE,        /* Rasterize                                  (fwd) */
+    BRUSH_STAGE_BWD_ZERO,         /* zero compact-order accumulators            (bwd) */
+    BRUSH_STAGE_RASTERIZE_BWD,    /* RasterizeBackwards                         (bwd) */
+    BRUSH_STAGE_PROJECT_BWD,      /* GatherGrads + ProjectBackwards (fused)     (bwd) */
+    BRUSH_NUM_STAGES
+};
+int brush_profiler_create(BrushProfiler **out);
+void brush_profiler_destroy(BrushProfiler *p);
+/* Attach (or detach with NULL) a profiler to the calling host thread. */
+void brush_profiler_attach(BrushProfiler *p);
+/* Blocks until the recorded events have completed, then writes the milliseconds spent in each
+ * stage of the LAST forward and LAST backward call recorded (0 for stages not recorded). */
+int brush_profiler_read(BrushProfiler *p, float *h_ms /* [BRUSH_NUM_STAGES] */);
+const char *brush_stage_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRUSH_HIP_H */

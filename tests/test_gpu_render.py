@@ -1,0 +1,319 @@
+"""GPU parity of the forward+backward rasterizer through the C ABI (pytest -m gpu).
+
+Three anchors:
+  1. the reference's golden vectors at its own tolerances (render.rs:815-830);
+  2. the CPU oracle on seeded clouds: every integer output bit-exact, floats within 1e-4;
+  3. size-independent properties at the headline size (1 M splats @1080p).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+PIX_TOL = 1e-4  # north-star tolerance on pixels (L-inf)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import brush_amd.render as R
+
+    R.DEBUG_POISON = True  # counterpart of the reference's -12345 buffer poison
+    return torch.device("cuda:0")
+
+
+def _camera(w, h):
+    import brush_amd
+
+    c = H.reference_test_camera(w, h)
+    return brush_amd.Camera(c["position"], c["rotation_xyzw"], c["fov_x"], c["fov_y"], c["center_uv"])
+
+
+def _t(a, dev, grad=False):
+    import torch
+
+    t = torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    if grad:
+        t.requires_grad_(True)
+    return t
+
+
+def _np_u32(t):
+    return t.detach().cpu().numpy().astype(np.int32).view(np.uint32)
+
+
+@pytest.mark.parametrize("case", ["tiny_case", "basic_case"])
+def test_reference_golden(dev, case):
+    """test_reference of render.rs:695-833 through Splats.render + autograd."""
+    import torch
+
+    import brush_amd
+
+    d = H.load_case(case)
+    h, w, _ = d["out_img"].shape
+    splats = brush_amd.Splats.from_safetensors(d, dev)
+    out, aux = splats.render(_camera(w, h), (w, h), False)
+    V = aux.read_num_visible()
+    assert V == d["means"].shape[0]
+    perm = aux.global_from_compact_gid[:V].long().cpu().numpy()
+    proj = aux.projected_splats.detach().cpu().numpy()
+
+    def chk(name, a, b, rtol, atol):
+        ok, err, bad = H.all_close_report(a, b, rtol, atol)
+        assert ok, f"{case}:{name} max_abs_err={err} bad={bad}"
+
+    chk("xys", proj[:V, 0:2], d["xys"][perm], 1e-4, 1e-10)
+    chk("conics", proj[:V, 2:5], d["conics"][perm], 1e-4, 5e-7)
+    out_rgb = out[..., :3]
+    chk("out_img", out_rgb.detach().cpu().numpy(), d["out_img"], 1e-4, 1e-9)
+    crab = torch.as_tensor(H.crab_rgb(), device=dev)
+    loss = ((out_rgb - crab) ** 2).mean()
+    loss.backward()
+    g = lambda p: p.grad.detach().cpu().numpy()
+    chk("v_xy", g(splats.xys_dummy), d["v_xy"], 1e-4, 1e-9)
+    chk("v_opacities", g(splats.raw_opacity), d["v_opacities"], 1e-4, 1e-10)
+    chk("v_coeffs", g(splats.sh_coeffs), d["v_coeffs"], 1e-4, 1e-9)
+    chk("v_scales", g(splats.log_scales), d["v_scales"], 1e-4, 1e-9)
+    chk("v_means", g(splats.means), d["v_means"], 1e-4, 1e-9)
+    chk("v_quats", g(splats.rotation), d["v_quats"], 1e-1, 1e-1)
+
+
+def test_renders_at_all(dev):
+    """render.rs:652-693"""
+    import torch
+
+    import brush_amd
+
+    n = 8
+    cam = brush_amd.Camera([0, 0, 0], [0, 0, 0, 1], 0.5, 0.5, (0.5, 0.5))
+    means = torch.zeros((n, 3), device=dev, requires_grad=True)
+    xy = torch.zeros((n, 2), device=dev, requires_grad=True)
+    log_scales = (torch.ones((n, 3), device=dev) * 2.0).requires_grad_(True)
+    quats = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=dev).repeat(n, 1).requires_grad_(True)
+    sh = torch.ones((n, 1, 3), device=dev, requires_grad=True)
+    raw = torch.zeros((n,), device=dev, requires_grad=True)
+    out, aux = brush_amd.render_splats(cam, (32, 32), means, xy, log_scales, quats, sh, raw, False)
+    assert abs(float(out[..., :3].mean())) < 1e-5
+    assert float(out[..., 3].mean()) == 0.0
+    assert aux.read_num_visible() == 0 and aux.read_num_intersections() == 0
+    out.mean().backward()
+    for p in (means, xy, log_scales, quats, sh, raw):
+        assert not bool(p.grad.any())
+
+
+def _run_pair(dev, cloud, w, h, sh_degree, max_intersects=None, v_out=None):
+    """Run the GPU op and the oracle on identical inputs (the oracle gets the uniform words the
+    GPU op actually used).  Returns (gpu dict, oracle dict)."""
+    import torch
+
+    import brush_amd
+    from brush_amd.render import uniforms_to_numpy
+
+    params = {k: _t(cloud[k], dev, grad=True) for k in ("means", "log_scales", "quats", "sh", "raw_opac")}
+    xy = torch.zeros((cloud["means"].shape[0], 2), device=dev, requires_grad=True)
+    out, aux = brush_amd.render_splats(_camera(w, h), (w, h), params["means"], xy, params["log_scales"],
+                                       params["quats"], params["sh"], params["raw_opac"], False, max_intersects)
+    u = uniforms_to_numpy(aux)
+    o_out, o_aux = O.render_forward(u, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["sh"],
+                                    cloud["raw_opac"], max_intersects=aux.max_intersects)
+    if v_out is None:
+        rng = np.random.default_rng(7)
+        v_out = (rng.standard_normal((h, w, 4)).astype(np.float32)) / np.float32(h * w)
+    out.backward(_t(v_out, dev))
+    o_g = O.render_backward(u, o_aux, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["raw_opac"],
+                            o_out, v_out)
+    gpu = dict(out=out.detach().cpu().numpy(), aux=aux, u=u,
+               v_means=params["means"].grad, v_scales=params["log_scales"].grad, v_quats=params["quats"].grad,
+               v_sh=params["sh"].grad, v_opac=params["raw_opac"].grad, v_xy=xy.grad)
+    return gpu, dict(out=o_out, aux=o_aux, grads=o_g)
+
+
+def _assert_forward_parity(gpu, orc, w, h):
+    aux, oa = gpu["aux"], orc["aux"]
+    V, I = int(oa["num_visible"][0]), int(oa["num_intersections"][0])
+    assert aux.read_num_visible() == V
+    assert gpu["u"]["num_visible"] == V  # uniforms_buffer word 25 (render.rs:145-149)
+    assert aux.read_num_intersections() == I
+    assert int(aux.overflow.item()) == int(oa["overflow"])
+    n = oa["global_from_compact_gid"].shape[0]
+    # integer / index outputs: bit-exact
+    assert np.array_equal(_np_u32(aux.global_from_compact_gid)[:n], oa["global_from_compact_gid"])
+    inv = _np_u32(aux.compact_from_global_gid)
+    want_inv = np.full(n, 0xFFFFFFFF, np.uint32)
+    want_inv[oa["global_from_compact_gid"][:V]] = np.arange(V, dtype=np.uint32)
+    assert np.array_equal(inv[:n], want_inv)
+    gp = aux.projected_splats.detach().cpu().numpy()[:V]
+    op = oa["projected_splats"][:V]
+    assert np.array_equal(gp.view(np.uint32), op.view(np.uint32)), "projected splats differ bitwise"
+    assert np.array_equal(_np_u32(aux.cum_tiles_hit)[:n], oa["cum_tiles_hit"])
+    assert np.array_equal(_np_u32(aux.compact_gid_from_isect)[:I], oa["compact_gid_from_isect"][:I])
+    assert np.array_equal(_np_u32(aux.tile_bins), oa["tile_bins"])
+    # composite: 1e-4 L-inf away from pixels where a threshold test is within 1e-5 of flipping
+    risk = oa["flip_risk"].astype(bool)
+    assert risk.mean() < 2e-3
+    diff = np.abs(gpu["out"] - orc["out"]).max(axis=2)
+    assert diff[~risk].max() <= PIX_TOL, f"max pixel err {diff[~risk].max()}"
+    assert diff.max() <= 2.0 / 255.0 + PIX_TOL
+    fi = _np_u32(aux.final_index)
+    assert np.array_equal(fi[~risk], oa["final_index"][~risk])
+    return V, I
+
+
+def _assert_grad_parity(gpu, orc, rtol=2e-4):
+    """f32 atomics vs the oracle's f64 tile sums: rtol on each tensor's scale."""
+    for name, key in (("v_means", "v_means"), ("v_scales", "v_scales"), ("v_quats", "v_quats"), ("v_sh", "v_sh"),
+                      ("v_opac", "v_opac"), ("v_xy", "v_xy")):
+        a = gpu[name].detach().cpu().numpy().astype(np.float64)
+        b = orc["grads"][key].astype(np.float64).reshape(a.shape)
+        scale = np.abs(b).max() + 1e-30
+        err = np.abs(a - b)
+        tol = rtol * np.abs(b) + 2e-5 * scale
+        assert (err <= tol).all(), f"{name}: max err {err.max():.3e} scale {scale:.3e} bad {(err > tol).sum()}"
+        # dense and exactly zero for non-visible splats
+        V = int(orc["aux"]["num_visible"][0])
+        vis = np.zeros(a.shape[0], bool)
+        vis[orc["aux"]["global_from_compact_gid"][:V]] = True
+        assert not a[~vis].any()
+
+
+@pytest.mark.parametrize("n,w,h,deg,mult", [
+    (2000, 123, 82, 3, 0.002),       # ragged image (not a tile multiple), every SH band
+    (20000, 256, 192, 0, 0.01),
+    (20000, 200, 120, 1, 0.01),
+    (20000, 200, 120, 2, 0.01),
+    (20000, 200, 120, 4, 0.01),
+    (150000, 640, 480, 3, 0.05),     # long tile lists (multiple LDS batches)
+    (300000, 800, 800, 0, 1.0),      # c2-sized, bench distribution
+])
+def test_matches_oracle(dev, n, w, h, deg, mult):
+    cloud = H.synthetic_cloud(n, deg, seed=4, mean_mult=mult)
+    gpu, orc = _run_pair(dev, cloud, w, h, deg, max_intersects=4_000_000)
+    V, I = _assert_forward_parity(gpu, orc, w, h)
+    assert V > 0 and I > 0
+    _assert_grad_parity(gpu, orc)
+
+
+def test_depth_ties_are_deterministic(dev):
+    """Equal depths: compaction keeps global order, so ties break by global id."""
+    cloud = H.synthetic_cloud(4000, 0, seed=9, mean_mult=0.002)
+    cloud["means"][:, 2] = np.round(cloud["means"][:, 2])  # many exact depth ties
+    gpu, orc = _run_pair(dev, cloud, 160, 96, 0)
+    _assert_forward_parity(gpu, orc, 160, 96)
+    V = gpu["aux"].read_num_visible()
+    gids = _np_u32(gpu["aux"].global_from_compact_gid)[:V]
+    depth = (cloud["means"][gids, 2] + 8.0)
+    same = depth[1:] == depth[:-1]
+    assert same.sum() > 100 and (gids[1:][same] > gids[:-1][same]).all()
+
+
+def test_intersection_overflow_is_flagged(dev):
+    """The reference truncates silently (map_gaussian_to_intersects.wgsl:40); the build clamps
+    num_intersections to the capacity and raises aux.overflow."""
+    cloud = H.synthetic_cloud(5000, 0, seed=3, mean_mult=0.002)
+    gpu, orc = _run_pair(dev, cloud, 160, 96, 0, max_intersects=1000)
+    assert int(gpu["aux"].overflow.item()) == 1 and orc["aux"]["overflow"]
+    assert gpu["aux"].read_num_intersections() == 1000
+    _assert_forward_parity(gpu, orc, 160, 96)
+
+
+def test_raster_u32(dev):
+    """Packed RGBA8 path (rasterize.wgsl:106-109) vs the oracle, allowing 1 LSB where the
+    float image differs by an exp() ulp."""
+    import brush_amd
+
+    cloud = H.synthetic_cloud(20000, 0, seed=4, mean_mult=0.01)
+    w, h = 256, 192
+    p = {k: _t(cloud[k], dev) for k in cloud}
+    out, aux = brush_amd.render_splats(_camera(w, h), (w, h), p["means"], None, p["log_scales"], p["quats"], p["sh"],
+                                       p["raw_opac"], True)
+    assert tuple(out.shape) == (h, w, 1)
+    from brush_amd.render import uniforms_to_numpy
+
+    o_out, _ = O.render_forward(uniforms_to_numpy(aux), cloud["means"], cloud["log_scales"], cloud["quats"],
+                                cloud["sh"], cloud["raw_opac"], raster_u32=True)
+    a = _np_u32(out[..., 0])
+    ch = lambda x, k: ((x >> (8 * k)) & 0xFF).astype(np.int32)
+    for k in range(4):
+        assert np.abs(ch(a, k) - ch(o_out, k)).max() <= 1
+    assert (a == o_out).mean() > 0.99
+
+
+def test_headline_size_properties(dev):
+    """1 M splats @1080p (BASELINE.json metric): structural invariants, run-to-run bit
+    reproducibility of the forward, linearity of the backward in v_out."""
+    import torch
+
+    import brush_amd
+
+    n, w, h = 1 << 20, 1920, 1080
+    cloud = H.synthetic_cloud(n, 0, seed=4)
+    p = {k: _t(cloud[k], dev) for k in cloud}
+
+    def run(scale):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        xy = torch.zeros((n, 2), device=dev, requires_grad=True)
+        out, aux = brush_amd.render_splats(_camera(w, h), (w, h), leaves["means"], xy, leaves["log_scales"],
+                                           leaves["quats"], leaves["sh"], leaves["raw_opac"], False, 4_000_000)
+        (out.mean() * scale).backward()
+        return out.detach(), aux, {k: v.grad for k, v in leaves.items()}, xy.grad
+
+    out1, aux1, g1, xy1 = run(1.0)
+    out2, aux2, g2, xy2 = run(2.0)
+    assert torch.equal(out1, out2) and torch.equal(aux1.final_index, aux2.final_index)
+    V, I = aux1.read_num_visible(), aux1.read_num_intersections()
+    assert 0 < V < n and 0 < I <= aux1.max_intersects and int(aux1.overflow.item()) == 0
+    # visible set is a set of distinct ids, inverse map is consistent
+    gfc = aux1.global_from_compact_gid[:V].long()
+    assert int(torch.bincount(gfc, minlength=n).max()) == 1
+    assert bool((aux1.compact_from_global_gid[gfc] == torch.arange(V, device=dev, dtype=torch.int32)).all())
+    assert bool((aux1.global_from_compact_gid[V:] == 0).all())
+    # cum_tiles_hit is non-decreasing, its tail equals I
+    cum = aux1.cum_tiles_hit.long()
+    assert bool((cum[1:] >= cum[:-1]).all()) and int(cum[-1]) == I and int(cum[V - 1]) == I
+    # tile bins partition [0, I)
+    bins = aux1.tile_bins.long().reshape(-1, 2)
+    used = bins[bins[:, 1] > bins[:, 0]]
+    assert int((used[:, 1] - used[:, 0]).sum()) == I
+    order = torch.argsort(used[:, 0])
+    assert bool((used[order][1:, 0] == used[order][:-1, 1]).all())
+    # per-tile lists are depth ordered (compact ids ascending within a tile)
+    cg = aux1.compact_gid_from_isect[:I].long()
+    starts = torch.zeros(I, dtype=torch.bool, device=dev)
+    starts[used[:, 0]] = True
+    assert bool(((cg[1:] > cg[:-1]) | starts[1:]).all())
+    # alpha in [0, 1), image finite
+    assert bool(torch.isfinite(out1).all()) and float(out1[..., 3].max()) < 1.0 and float(out1[..., 3].min()) >= 0.0
+    # backward is linear in v_out (f32 atomics: tolerance), dense, zero off the visible set
+    for k in g1:
+        a, b = g1[k].double() * 2.0, g2[k].double()
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 1e-4 * scale, k
+        vis = torch.zeros(n, dtype=torch.bool, device=dev)
+        vis[gfc] = True
+        assert not bool(g1[k][~vis].any())
+    assert float((xy1.double() * 2 - xy2.double()).abs().max()) <= 1e-4 * (float(xy2.abs().max()) + 1e-30)
+
+
+def test_rejects_bad_shapes(dev):
+    import torch
+
+    import brush_amd
+
+    n = 4
+    ok = dict(means=torch.zeros((n, 3), device=dev), log_scales=torch.zeros((n, 3), device=dev),
+              quats=torch.zeros((n, 4), device=dev), sh=torch.zeros((n, 1, 3), device=dev),
+              raw=torch.zeros((n,), device=dev))
+    cam = _camera(32, 32)
+    with pytest.raises(AssertionError):  # DimCheck (render.rs:74-79)
+        brush_amd.render_splats(cam, (32, 32), ok["means"], None, torch.zeros((n, 2), device=dev), ok["quats"],
+                                ok["sh"], ok["raw"])
+    with pytest.raises(ValueError):  # render.rs:44-52
+        brush_amd.render_splats(cam, (32, 32), ok["means"], None, ok["log_scales"], ok["quats"],
+                                torch.zeros((n, 5, 3), device=dev), ok["raw"])

@@ -1,0 +1,89 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/brush_hip.h,
+argument validation works without a GPU, host camera/uniform packing mirrors camera.rs."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as G
+
+    if not os.path.exists(os.path.join(ROOT, "brush_amd", "lib", "libbrush_hip.so")):
+        G.build()
+    from brush_amd import _lib
+
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "brush_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(brush_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 12
+    from brush_amd import _lib
+
+    assert sorted(_lib.SYMBOL_NAMES) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.brush_version()
+
+
+def test_argument_validation_without_gpu(lib):
+    from brush_amd import _lib
+
+    n = C.c_size_t()
+    assert lib.brush_fwd_workspace_size(1 << 20, 1920, 1080, 3, 8388480, C.byref(n)) == 0 and n.value > 0
+    assert lib.brush_fwd_workspace_size(10, 32, 32, 5, 100, C.byref(n)) == -1  # sh_degree > 4
+    assert lib.brush_bwd_workspace_size(1 << 20, 1920, 1080, 3, C.byref(n)) == 0 and n.value >= (1 << 20) * 36
+    assert lib.brush_radix_argsort_workspace_size(1000, C.byref(n)) == 0 and n.value >= 8000
+    assert lib.brush_inclusive_scan_workspace_size(1000, C.byref(n)) == 0 and n.value > 0
+    # bits > 32 is rejected before any device work (brush-sort/src/lib.rs:38-39)
+    assert lib.brush_radix_argsort_u32(None, None, None, None, None, 16, 33, None, 0, None) == -1
+    assert lib.brush_radix_argsort_u32(None, None, None, None, None, 16, 32, None, 0, None) == -1  # null ptrs
+    assert lib.brush_render_forward(None, None, None, None, None, None, 0, 0, None, None, None, 0, None) == -1
+    assert lib.brush_status_string(-2) == b"workspace too small"
+    # render.rs:204-206
+    assert lib.brush_default_max_intersects(1 << 20, 1920, 1080) == 128 * 65535
+    assert lib.brush_default_max_intersects(10, 32, 32) == 40
+    assert _lib.BrushUniforms and C.sizeof(_lib.BrushUniforms) == 28 * 4
+
+
+def test_camera_matches_reference_test_setup():
+    """camera.rs:28-58 and the uniform packing of render.rs:102-116 vs the oracle's restatement."""
+    import brush_amd
+    from brush_amd.render import pack_uniforms
+    from oracle import oracle as O
+
+    w, h = 123, 82
+    focal = brush_amd.fov_to_focal(math.pi * 0.5, w)
+    assert abs(focal - 61.5) < 1e-12
+    cam = brush_amd.Camera([0.3, -0.2, -8.0], [0.1, 0.2, 0.3, math.sqrt(1 - 0.14)], brush_amd.focal_to_fov(focal, w),
+                           brush_amd.focal_to_fov(focal, h), (0.5, 0.5))
+    u = pack_uniforms(cam, (w, h), 3, 10)
+    o = O.make_uniforms(cam.position, cam.rotation, cam.fov_x, cam.fov_y, cam.center_uv, (w, h), 3)
+    assert np.allclose(np.array(u.viewmat[:]), o["viewmat"], atol=1e-6)
+    assert np.allclose(np.array(u.focal[:]), o["focal"]) and np.allclose(np.array(u.pixel_center[:]), o["pixel_center"])
+    assert list(u.tile_bounds[:]) == [8, 6] and list(u.img_size[:]) == [w, h]
+    # world_to_local really inverts local_to_world
+    assert np.allclose(cam.world_to_local().astype(np.float64) @ cam.local_to_world(), np.eye(4), atol=1e-6)
+
+
+def test_no_cpu_fallback():
+    """The op refuses CPU tensors instead of silently computing elsewhere."""
+    import torch
+
+    import brush_amd
+
+    cam = brush_amd.Camera([0, 0, -8], [0, 0, 0, 1], 1.0, 1.0)
+    z = torch.zeros
+    with pytest.raises(AssertionError, match="no CPU path"):
+        brush_amd.render_splats(cam, (32, 32), z((4, 3)), None, z((4, 3)), z((4, 4)), z((4, 1, 3)), z((4,)))
+    with pytest.raises(AssertionError):
+        brush_amd.prefix_sum(torch.zeros(4, dtype=torch.int32))
