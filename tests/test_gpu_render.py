@@ -167,14 +167,21 @@ def _assert_forward_parity(gpu, orc, w, h):
 
 
 def _assert_grad_parity(gpu, orc, rtol=2e-4):
-    """f32 atomics vs the oracle's f64 tile sums: rtol on each tensor's scale."""
-    for name, key in (("v_means", "v_means"), ("v_scales", "v_scales"), ("v_quats", "v_quats"), ("v_sh", "v_sh"),
-                      ("v_opac", "v_opac"), ("v_xy", "v_xy")):
+    """GPU (f32 wave sums + f32 atomics, unspecified order) vs the oracle (f64 tile sums).
+
+    |a-b| <= rtol*|b| + atol_frac*max|b|.  v_sh / v_opac / v_xy are direct sums (atol 2e-5 of
+    the tensor's scale); v_means / v_scales / v_quats pass the ~1e-6-relative differences in
+    v_conic through the ill-conditioned cov2d->cov3d->quat VJP (cancellation across terms of
+    size scale^2), so they get 2e-4 of the tensor's scale.  The reference's own test holds
+    v_quats to 1e-1 and the others to rtol 1e-4 (render.rs:815-830)."""
+    for name, key, atol_frac in (("v_means", "v_means", 2e-4), ("v_scales", "v_scales", 2e-4),
+                                 ("v_quats", "v_quats", 2e-4), ("v_sh", "v_sh", 2e-5), ("v_opac", "v_opac", 2e-5),
+                                 ("v_xy", "v_xy", 2e-5)):
         a = gpu[name].detach().cpu().numpy().astype(np.float64)
         b = orc["grads"][key].astype(np.float64).reshape(a.shape)
         scale = np.abs(b).max() + 1e-30
         err = np.abs(a - b)
-        tol = rtol * np.abs(b) + 2e-5 * scale
+        tol = rtol * np.abs(b) + atol_frac * scale
         assert (err <= tol).all(), f"{name}: max err {err.max():.3e} scale {scale:.3e} bad {(err > tol).sum()}"
         # dense and exactly zero for non-visible splats
         V = int(orc["aux"]["num_visible"][0])
