@@ -14,6 +14,8 @@ constexpr uint32_t kWave = 64;                          // CDNA wavefront
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 constexpr uint32_t kUniformWords = 28;
 constexpr uint32_t kNumVisibleWord = 25;                // render.rs:145-149
+// Compact-order gradient rows of the backward: [v_xy(2) v_conic(3) v_rgb(3) v_opac(1) pad(3)].
+constexpr uint32_t kCompactStride = 12;
 
 // Records the failing hipError_t for brush_last_hip_error().
 void set_last_hip_error(int e);

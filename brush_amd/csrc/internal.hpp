@@ -32,16 +32,15 @@ hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
 hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                                      const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
                                      const float *projected, const uint32_t *final_index,
-                                     const float *out_img, const float *v_out, float *v_xy_local,
-                                     float *v_conics, float *v_colors, hipStream_t s);
+                                     const float *out_img, const float *v_out, float *v_compact,
+                                     hipStream_t s);
 
 // project_bwd.hip
 hipError_t launch_project_backward(const ViewParams &vp, const float *means, const float *log_scales,
                                    const float *quats, const float *raw_opac,
-                                   const uint32_t *compact_from_global, const float *v_xy_local,
-                                   const float *v_conics, const float *v_colors, float *v_means, float *v_xy,
+                                   const uint32_t *compact_from_global, const float *v_compact,
+                                   float *v_means, float *v_xy,
                                    float *v_scales, float *v_quats, float *v_sh, float *v_opac, hipStream_t s);
-hipError_t launch_zero_compact_grads(const uint32_t *num_visible, uint32_t n, float *v_xy_local,
-                                     float *v_conics, float *v_colors, hipStream_t s);
+hipError_t launch_zero_compact_grads(const uint32_t *num_visible, uint32_t n, float *v_compact, hipStream_t s);
 
 }  // namespace brush

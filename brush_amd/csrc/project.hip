@@ -29,6 +29,115 @@ namespace brush {
 namespace {
 
 constexpr uint32_t kThreads = 256;
+// Bboxes above this many tiles are walked by the whole wave (64 tiles per step) instead of by
+// their owning lane: the nearest splats cover thousands of tiles and sit in adjacent lanes.
+constexpr uint32_t kCoopArea = 32;
+
+// Compact ids are in depth order, so the nearest (largest-footprint) splats are neighbours.
+// To keep them out of one wave, lane t of block b takes the 4 consecutive ids of group
+// (t/4)*gridDim + b: neighbours in depth order land in different workgroups, while each
+// group's 4 x 36 B records still form one contiguous 144-byte run.
+__device__ __forceinline__ uint32_t interleaved_id(uint32_t round, uint32_t tid, uint32_t bid, uint32_t nblocks) {
+    return round * (nblocks * kThreads) + (((tid >> 2) * nblocks + bid) << 2) + (tid & 3u);
+}
+
+__device__ __forceinline__ float bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+}
+
+// Number of bbox tiles that pass can_be_visible for this lane's splat.  Must be called by all
+// 64 lanes of the wave (inactive lanes pass active = false).
+__device__ __forceinline__ uint32_t count_tiles(bool active, const uint32_t bb[4], const TileTest &tt,
+                                                const float xy[2]) {
+    const uint32_t bw = bb[2] - bb[0], bh = bb[3] - bb[1];
+    const uint32_t area = active ? bw * bh : 0u;
+    const bool big = area > kCoopArea;
+    uint32_t cnt = 0;
+    if (active && !big) {
+        for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
+            for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
+                if (can_be_visible(tt, tx, ty, xy)) cnt++;
+    }
+    uint64_t m = __ballot(big);
+    const uint32_t lane = lane_id();
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        TileTest st;
+        st.q[0] = bcast(tt.q[0], src);
+        st.q[1] = bcast(tt.q[1], src);
+        st.q[2] = bcast(tt.q[2], src);
+        st.any = bcast((uint32_t)tt.any, src) != 0;
+        const float sxy[2] = {bcast(xy[0], src), bcast(xy[1], src)};
+        const uint32_t sb0 = bcast(bb[0], src), sb1 = bcast(bb[1], src);
+        const uint32_t sbw = bcast(bw, src), sarea = bcast(area, src);
+        uint32_t c = 0;
+        for (uint32_t i0 = 0; i0 < sarea; i0 += kWave) {
+            const uint32_t i = i0 + lane;
+            bool hit = false;
+            if (i < sarea) hit = can_be_visible(st, sb0 + i % sbw, sb1 + i / sbw, sxy);
+            c += __popcll(__ballot(hit));
+        }
+        if ((int)lane == src) cnt = c;
+    }
+    return cnt;
+}
+
+// Emits (tile id, compact gid) for every passing bbox tile in row-major order starting at
+// `isect`.  Same calling convention as count_tiles.
+__device__ __forceinline__ void emit_tiles(bool active, uint32_t c, uint32_t isect, const uint32_t bb[4],
+                                           const TileTest &tt, const float xy[2], uint32_t tbx, uint32_t cap,
+                                           uint32_t *__restrict__ tile_ids, uint32_t *__restrict__ gids) {
+    const uint32_t bw = bb[2] - bb[0], bh = bb[3] - bb[1];
+    const uint32_t area = active ? bw * bh : 0u;
+    const bool big = area > kCoopArea;
+    if (active && !big) {
+        for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
+            for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
+                if (can_be_visible(tt, tx, ty, xy) && isect < cap) {
+                    tile_ids[isect] = tx + ty * tbx;
+                    gids[isect] = c;
+                    isect++;
+                }
+    }
+    uint64_t m = __ballot(big);
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        TileTest st;
+        st.q[0] = bcast(tt.q[0], src);
+        st.q[1] = bcast(tt.q[1], src);
+        st.q[2] = bcast(tt.q[2], src);
+        st.any = bcast((uint32_t)tt.any, src) != 0;
+        const float sxy[2] = {bcast(xy[0], src), bcast(xy[1], src)};
+        const uint32_t sb0 = bcast(bb[0], src), sb1 = bcast(bb[1], src);
+        const uint32_t sbw = bcast(bw, src), sarea = bcast(area, src);
+        const uint32_t sc = bcast(c, src);
+        uint32_t run = bcast(isect, src);
+        for (uint32_t i0 = 0; i0 < sarea; i0 += kWave) {
+            const uint32_t i = i0 + lane;
+            bool hit = false;
+            uint32_t tx = 0, ty = 0;
+            if (i < sarea) {
+                tx = sb0 + i % sbw;
+                ty = sb1 + i / sbw;
+                hit = can_be_visible(st, tx, ty, sxy);
+            }
+            const uint64_t b = __ballot(hit);
+            const uint32_t pos = run + __popcll(b & lt);
+            if (hit && pos < cap) {
+                tile_ids[pos] = tx + ty * tbx;
+                gids[pos] = sc;
+            }
+            run += __popcll(b);
+        }
+    }
+}
 
 // ---- init: uniforms buffer, counters, tile bins -----------------------------------------
 __global__ __launch_bounds__(kThreads) void k_init(BrushUniforms u, uint32_t *__restrict__ uniforms_buffer,
@@ -152,77 +261,85 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
     const uint32_t V = *num_visible;
     const uint32_t n = vp.total_splats;
     const uint32_t ncoef = (vp.sh_degree + 1) * (vp.sh_degree + 1);
-    for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < n; c += gridDim.x * kThreads) {
-        if (c >= V) {
-            global_from_compact[c] = 0;
-            continue;
-        }
-        const uint32_t g = global_from_compact[c];
-        compact_from_global[g] = c;
-        const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
-        const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
-                                det_expf(log_scales[(size_t)g * 3 + 2])};
-        const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
-        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float opac = det_sigmoid(raw_opac[g]);
-        float p_view[3], cov2d[3], conic[3], xy[2];
-        to_view(vp, mean, p_view);
-        calc_cov2d(vp, p_view, scale, quat, cov2d);
-        cov_to_conic(cov2d, conic);
-        project_pix(vp, p_view, xy);
+    // Block-uniform trip count: every lane of a wave reaches count_tiles() together.
+    const uint32_t rounds = (n + gridDim.x * kThreads - 1) / (gridDim.x * kThreads);
+    for (uint32_t round = 0; round < rounds; round++) {
+        const uint32_t c = interleaved_id(round, threadIdx.x, blockIdx.x, gridDim.x);
+        if (c < n && c >= V) global_from_compact[c] = 0;
+        const bool active = c < V;
+        float xy[2] = {0.f, 0.f}, conic[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
+        float opac = 0.f;
+        uint32_t bb[4] = {0, 0, 0, 0};
+        TileTest tt;
+        tt.q[0] = tt.q[1] = tt.q[2] = 0.f;
+        tt.any = false;
+        if (active) {
+            const uint32_t g = global_from_compact[c];
+            compact_from_global[g] = c;
+            const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
+            const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
+                                    det_expf(log_scales[(size_t)g * 3 + 2])};
+            const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
+            const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+            opac = det_sigmoid(raw_opac[g]);
+            float p_view[3], cov2d[3];
+            to_view(vp, mean, p_view);
+            calc_cov2d(vp, p_view, scale, quat, cov2d);
+            cov_to_conic(cov2d, conic);
+            project_pix(vp, p_view, xy);
 
-        // SH -> colour, evaluated with the WGSL expression tree (project_visible.wgsl:51-147).
-        float dir[3];
-        view_dir(vp, mean, dir);
-        float Y[25];
-        sh_basis<25>(vp.sh_degree, dir, Y);
-        const float *sh = sh_coeffs + (size_t)g * ncoef * 3;
-        float rgb[3];
+            // SH -> colour, evaluated with the WGSL expression tree (project_visible.wgsl:51-147).
+            float dir[3];
+            view_dir(vp, mean, dir);
+            float Y[25];
+            sh_basis<25>(vp.sh_degree, dir, Y);
+            const float *sh = sh_coeffs + (size_t)g * ncoef * 3;
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            float col = Y[0] * sh[ch];
-            if (vp.sh_degree >= 1) {
-                const float inner = ((-dir[1]) * sh[1 * 3 + ch] + dir[2] * sh[2 * 3 + ch]) - dir[0] * sh[3 * 3 + ch];
-                col = col + 0.48860251190292f * inner;
+            for (int ch = 0; ch < 3; ch++) {
+                float col = Y[0] * sh[ch];
+                if (vp.sh_degree >= 1) {
+                    const float inner =
+                        ((-dir[1]) * sh[1 * 3 + ch] + dir[2] * sh[2 * 3 + ch]) - dir[0] * sh[3 * 3 + ch];
+                    col = col + 0.48860251190292f * inner;
+                }
+                if (vp.sh_degree >= 2) {
+                    float acc = Y[4] * sh[4 * 3 + ch];
+#pragma unroll
+                    for (int k = 5; k < 9; k++) acc = acc + Y[k] * sh[k * 3 + ch];
+                    col = col + acc;
+                }
+                if (vp.sh_degree >= 3) {
+                    float acc = Y[9] * sh[9 * 3 + ch];
+#pragma unroll
+                    for (int k = 10; k < 16; k++) acc = acc + Y[k] * sh[k * 3 + ch];
+                    col = col + acc;
+                }
+                if (vp.sh_degree >= 4) {
+                    float acc = Y[16] * sh[16 * 3 + ch];
+#pragma unroll
+                    for (int k = 17; k < 25; k++) acc = acc + Y[k] * sh[k * 3 + ch];
+                    col = col + acc;
+                }
+                rgb[ch] = col + 0.5f;
             }
-            if (vp.sh_degree >= 2) {
-                float acc = Y[4] * sh[4 * 3 + ch];
-                for (int k = 5; k < 9; k++) acc = acc + Y[k] * sh[k * 3 + ch];
-                col = col + acc;
-            }
-            if (vp.sh_degree >= 3) {
-                float acc = Y[9] * sh[9 * 3 + ch];
-                for (int k = 10; k < 16; k++) acc = acc + Y[k] * sh[k * 3 + ch];
-                col = col + acc;
-            }
-            if (vp.sh_degree >= 4) {
-                float acc = Y[16] * sh[16 * 3 + ch];
-                for (int k = 17; k < 25; k++) acc = acc + Y[k] * sh[k * 3 + ch];
-                col = col + acc;
-            }
-            rgb[ch] = col + 0.5f;
+            const uint32_t radius = radius_from_conic(conic);
+            get_tile_bbox(xy, radius, vp.tile_bounds, bb);
+            tt = make_tile_test(conic, opac);
         }
-
-        const uint32_t radius = radius_from_conic(conic);
-        uint32_t bb[4];
-        get_tile_bbox(xy, radius, vp.tile_bounds, bb);
-        const TileTest tt = make_tile_test(conic, opac);
-        uint32_t area = 0;
-        for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
-            for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
-                if (can_be_visible(tt, tx, ty, xy)) area++;
-
-        float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
-        p[0] = xy[0];
-        p[1] = xy[1];
-        p[2] = conic[0];
-        p[3] = conic[1];
-        p[4] = conic[2];
-        p[5] = rgb[0];
-        p[6] = rgb[1];
-        p[7] = rgb[2];
-        p[8] = opac;
-        tiles_hit[c] = area;
+        const uint32_t area = count_tiles(active, bb, tt, xy);
+        if (active) {
+            float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
+            p[0] = xy[0];
+            p[1] = xy[1];
+            p[2] = conic[0];
+            p[3] = conic[1];
+            p[4] = conic[2];
+            p[5] = rgb[0];
+            p[6] = rgb[1];
+            p[7] = rgb[2];
+            p[8] = opac;
+            tiles_hit[c] = area;
+        }
     }
 }
 
@@ -234,23 +351,28 @@ __global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, cons
                                                              uint32_t cap, uint32_t *__restrict__ tile_ids,
                                                              uint32_t *__restrict__ gids) {
     const uint32_t V = *num_visible;
-    for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < V; c += gridDim.x * kThreads) {
-        const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
-        const float xy[2] = {p[0], p[1]};
-        const float conic[3] = {p[2], p[3], p[4]};
-        const float opac = p[8];
-        const uint32_t radius = radius_from_conic(conic);
-        uint32_t bb[4];
-        get_tile_bbox(xy, radius, vp.tile_bounds, bb);
-        const TileTest tt = make_tile_test(conic, opac);
-        uint32_t isect = c > 0 ? cum_tiles_hit[c - 1] : 0u;
-        for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
-            for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
-                if (can_be_visible(tt, tx, ty, xy) && isect < cap) {
-                    tile_ids[isect] = tx + ty * vp.tile_bounds[0];
-                    gids[isect] = c;
-                    isect++;
-                }
+    const uint32_t rounds = (V + gridDim.x * kThreads - 1) / (gridDim.x * kThreads);
+    for (uint32_t round = 0; round < rounds; round++) {
+        const uint32_t c = interleaved_id(round, threadIdx.x, blockIdx.x, gridDim.x);
+        const bool active = c < V;
+        float xy[2] = {0.f, 0.f};
+        uint32_t bb[4] = {0, 0, 0, 0};
+        uint32_t isect = 0;
+        TileTest tt;
+        tt.q[0] = tt.q[1] = tt.q[2] = 0.f;
+        tt.any = false;
+        if (active) {
+            const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
+            xy[0] = p[0];
+            xy[1] = p[1];
+            const float conic[3] = {p[2], p[3], p[4]};
+            const float opac = p[8];
+            const uint32_t radius = radius_from_conic(conic);
+            get_tile_bbox(xy, radius, vp.tile_bounds, bb);
+            tt = make_tile_test(conic, opac);
+            isect = c > 0 ? cum_tiles_hit[c - 1] : 0u;
+        }
+        emit_tiles(active, c, isect, bb, tt, xy, vp.tile_bounds[0], cap, tile_ids, gids);
     }
 }
 

@@ -56,23 +56,19 @@ __device__ __forceinline__ void cov2d_to_conic_vjp(const float conic[3], const f
 }
 
 __global__ __launch_bounds__(kThreads) void k_zero_compact_grads(const uint32_t *__restrict__ num_visible,
-                                                                 uint32_t n, float *__restrict__ v_xy_local,
-                                                                 float *__restrict__ v_conics,
-                                                                 float *__restrict__ v_colors) {
+                                                                 uint32_t n, float4 *__restrict__ v_compact) {
     const uint32_t V = min(*num_visible, n);
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t i = gtid; i < V * 2; i += stride) v_xy_local[i] = 0.0f;
-    for (uint32_t i = gtid; i < V * 3; i += stride) v_conics[i] = 0.0f;
-    for (uint32_t i = gtid; i < V * 4; i += stride) v_colors[i] = 0.0f;
+    const uint32_t words = V * (kCompactStride / 4);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x)
+        v_compact[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 template <int DEG>
 __global__ __launch_bounds__(kThreads) void k_project_backward(
     ViewParams vp, const float *__restrict__ means, const float *__restrict__ log_scales,
     const float *__restrict__ quats, const float *__restrict__ raw_opac,
-    const uint32_t *__restrict__ compact_from_global, const float *__restrict__ v_xy_local,
-    const float *__restrict__ v_conics, const float *__restrict__ v_colors, float *__restrict__ v_means,
+    const uint32_t *__restrict__ compact_from_global, const float *__restrict__ v_compact,
+    float *__restrict__ v_means,
     float *__restrict__ v_xy, float *__restrict__ v_scales, float *__restrict__ v_quats,
     float *__restrict__ v_sh, float *__restrict__ v_opac) {
     const uint32_t g = blockIdx.x * kThreads + threadIdx.x;
@@ -88,12 +84,14 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     for (uint32_t k = 0; k < ncoef; k++) Y[k] = 0.f;
 
     if (c != kInvalid) {
-        const float vxy[2] = {v_xy_local[(size_t)c * 2], v_xy_local[(size_t)c * 2 + 1]};
-        const float vconic[3] = {v_conics[(size_t)c * 3], v_conics[(size_t)c * 3 + 1], v_conics[(size_t)c * 3 + 2]};
-        const float4 vc4 = reinterpret_cast<const float4 *>(v_colors)[c];
-        vcol[0] = vc4.x;
-        vcol[1] = vc4.y;
-        vcol[2] = vc4.z;
+        const float4 *row = reinterpret_cast<const float4 *>(v_compact) + (size_t)c * (kCompactStride / 4);
+        const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+        const float vxy[2] = {r0.x, r0.y};
+        const float vconic[3] = {r0.z, r0.w, r1.x};
+        vcol[0] = r1.y;
+        vcol[1] = r1.z;
+        vcol[2] = r1.w;
+        const float v_alpha_sum = r2.x;
 
         const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
         const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
@@ -106,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
         view_dir(vp, mean, dir);
         sh_basis<ncoef>(DEG, dir, Y);
         const float sg = det_sigmoid(raw_opac[g]);
-        o_opac = vc4.w * (sg * (1.0f - sg));
+        o_opac = v_alpha_sum * (sg * (1.0f - sg));
         o_xy[0] = vxy[0];
         o_xy[1] = vxy[1];
 
@@ -210,25 +208,23 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
 
 }  // namespace
 
-hipError_t launch_zero_compact_grads(const uint32_t *num_visible, uint32_t n, float *v_xy_local, float *v_conics,
-                                     float *v_colors, hipStream_t s) {
-    const uint32_t grid = max(1u, min(ceil_div(n * 4u, kThreads), 1024u));
-    hipLaunchKernelGGL(k_zero_compact_grads, dim3(grid), dim3(kThreads), 0, s, num_visible, n, v_xy_local,
-                       v_conics, v_colors);
+hipError_t launch_zero_compact_grads(const uint32_t *num_visible, uint32_t n, float *v_compact, hipStream_t s) {
+    const uint32_t grid = max(1u, min(ceil_div(n * 3u, kThreads), 1024u));
+    hipLaunchKernelGGL(k_zero_compact_grads, dim3(grid), dim3(kThreads), 0, s, num_visible, n,
+                       reinterpret_cast<float4 *>(v_compact));
     return hipGetLastError();
 }
 
 hipError_t launch_project_backward(const ViewParams &vp, const float *means, const float *log_scales,
                                    const float *quats, const float *raw_opac,
-                                   const uint32_t *compact_from_global, const float *v_xy_local,
-                                   const float *v_conics, const float *v_colors, float *v_means, float *v_xy,
-                                   float *v_scales, float *v_quats, float *v_sh, float *v_opac, hipStream_t s) {
+                                   const uint32_t *compact_from_global, const float *v_compact, float *v_means,
+                                   float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
+                                   hipStream_t s) {
     if (vp.total_splats == 0) return hipSuccess;
     const dim3 grid(ceil_div(vp.total_splats, kThreads)), block(kThreads);
 #define BRUSH_LAUNCH_PB(D)                                                                                   \
     hipLaunchKernelGGL(k_project_backward<D>, grid, block, 0, s, vp, means, log_scales, quats, raw_opac,     \
-                       compact_from_global, v_xy_local, v_conics, v_colors, v_means, v_xy, v_scales, v_quats, \
-                       v_sh, v_opac)
+                       compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac)
     switch (vp.sh_degree) {
         case 0: BRUSH_LAUNCH_PB(0); break;
         case 1: BRUSH_LAUNCH_PB(1); break;

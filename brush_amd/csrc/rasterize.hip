@@ -4,28 +4,36 @@
 //   Rasterize           crates/brush-render/src/shaders/rasterize.wgsl:20-115
 //   RasterizeBackwards  crates/brush-render/src/shaders/rasterize_backwards.wgsl:140-304
 //
-// Both kernels: one 256-thread workgroup (4 wave64) per 16x16 tile, one pixel per lane; wave w
-// owns pixel rows 4w..4w+3.  The tile's depth-sorted splat list is staged in LDS in batches of
-// 256 records as two float4 + one float (broadcast ds_read_b128 x2 + ds_read_b32 per splat,
-// conflict-free because all lanes read one address).
+// gfx950 layout (both kernels): ONE wave64 per 16x16 tile, FOUR horizontally adjacent pixels
+// per lane (lane l -> row l/4, columns 4*(l%4)..+3).  A single-wave workgroup needs no
+// s_barrier and no LDS atomics; the tile's depth-sorted splat list is staged in LDS in batches
+// of 64 records (one gathered 36-byte record per lane) and read back as wave-uniform
+// broadcasts (2 x ds_read_b128 + 1 x ds_read_b32 per splat, shared by 4 pixel evaluations per
+// lane).  Workgroups are dealt to XCDs round-robin, so block ids are remapped to give every
+// XCD a contiguous band of tiles: neighbouring tiles gather the same splat records from one L2.
 //
-// Forward adds a workgroup-wide early exit once every pixel has saturated (the reference walks
-// all batches, rasterize.wgsl:57-101; results are identical).
+// Forward: identical arithmetic to the reference per pixel; the wave leaves the list as soon as
+// all of its 256 pixels have saturated (the reference walks every batch, rasterize.wgsl:57-101;
+// same result).
 //
-// Backward replaces the reference's LDS gradient queue + 9 software CAS loops per queued
-// gradient (rasterize_backwards.wgsl:47-135,276-301) by: wave64 DPP/shuffle reduction of the 9
-// components, LDS float atomics across the 4 waves into a per-batch [256][9] accumulator, and
-// ONE hardware global_atomic_add_f32 per (tile, splat, component) when the batch retires.
-// Waves in which no pixel is touched by a splat skip its reduction entirely.
+// Backward: replaces the reference's LDS gradient queue + nine software CAS loops per queued
+// gradient (rasterize_backwards.wgsl:47-135,276-301).  Each lane first sums the 9 gradient
+// components over its 4 pixels (fused into the FMAs), then ONE wave64 DPP reduction per
+// component (row_shr 1/2/4/8 + row_bcast 15/31, pure VALU) leaves the tile total in lane 63,
+// which parks it in an LDS row.  When a batch retires, the [64][9] block is flushed with
+// hardware global_atomic_add_f32 in a shape where consecutive lanes hit consecutive components
+// of one splat (contiguous 36-byte segments).  Splats that touch no pixel of the tile skip the
+// reduction.
 //
-// Roofline: these two kernels are fp32-VALU / v_exp_f32 / LDS-broadcast bound, not HBM bound
-// (256 pixel evaluations per 40-byte intersection record); DESIGN.md states both ceilings.
+// Roofline: both kernels are fp32-VALU / v_exp_f32 bound, not HBM bound (256 pixel evaluations
+// per 40-byte intersection record); DESIGN.md states both ceilings.
 #include "internal.hpp"
 
 namespace brush {
 namespace {
 
-constexpr uint32_t kBatch = kTileSize;  // 256 splats per LDS batch
+constexpr uint32_t kBatch = kWave;  // 64 splats per LDS batch, one per lane
+constexpr uint32_t kPix = 4;        // pixels per lane
 
 struct SplatLds {
     float4 a[kBatch];  // xy.x, xy.y, conic.x, conic.y
@@ -39,76 +47,100 @@ __device__ __forceinline__ void stage_splat(SplatLds &lds, uint32_t slot, const 
     lds.o[slot] = p[8];
 }
 
+// Every XCD (blocks b, b+8, b+16, ... share one) gets a contiguous band of tile ids.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t num_tiles) {
+    const uint32_t per = (num_tiles + 7u) / 8u;
+    return (bid & 7u) * per + (bid >> 3);
+}
+
 template <bool RASTER_U32>
-__global__ __launch_bounds__(kTileSize) void k_rasterize(uint32_t w, uint32_t h, uint32_t tbx,
-                                                         const uint32_t *__restrict__ gid_from_isect,
-                                                         const uint32_t *__restrict__ tile_bins,
-                                                         const float *__restrict__ projected,
-                                                         void *__restrict__ out_img,
-                                                         uint32_t *__restrict__ final_index) {
+__global__ __launch_bounds__(kWave) void k_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles,
+                                                     const uint32_t *__restrict__ gid_from_isect,
+                                                     const uint32_t *__restrict__ tile_bins,
+                                                     const float *__restrict__ projected,
+                                                     void *__restrict__ out_img,
+                                                     uint32_t *__restrict__ final_index) {
     __shared__ SplatLds lds;
-    const uint32_t tile_id = blockIdx.x;
+    const uint32_t tile_id = xcd_tile(blockIdx.x, num_tiles);
+    if (tile_id >= num_tiles) return;
     const uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t px = tile_x * kTileWidth + (tid % kTileWidth);
-    const uint32_t py = tile_y * kTileWidth + (tid / kTileWidth);
-    const bool inside = px < w && py < h;
-    const float pcx = (float)px + 0.5f, pcy = (float)py + 0.5f;  // rasterize.wgsl:32
-    bool done = !inside;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t px0 = tile_x * kTileWidth + (lane & 3u) * kPix;
+    const uint32_t py = tile_y * kTileWidth + (lane >> 2);
+    const float pcy = (float)py + 0.5f;  // rasterize.wgsl:32
+    const float pcx0 = (float)px0 + 0.5f;
+
+    bool done[kPix];
+    float T[kPix], cr[kPix], cg[kPix], cb[kPix];
+    uint32_t fin[kPix];
+#pragma unroll
+    for (uint32_t j = 0; j < kPix; j++) {
+        done[j] = !(px0 + j < w && py < h);
+        T[j] = 1.0f;
+        cr[j] = cg[j] = cb[j] = 0.0f;
+        fin[j] = 0;
+    }
 
     const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
-    float T = 1.0f;
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    uint32_t final_idx = 0;
-
     for (uint32_t batch_start = r0; batch_start < r1; batch_start += kBatch) {
-        // Workgroup-wide early exit; also the barrier that protects the LDS batch.
-        if (__syncthreads_count(!done) == 0) break;
+        if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
         const uint32_t remaining = min(kBatch, r1 - batch_start);
-        if (tid < remaining) {
-            const uint32_t cg_id = gid_from_isect[batch_start + tid];
-            stage_splat(lds, tid, projected + (size_t)cg_id * BRUSH_PROJECTED_FLOATS);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < remaining) {
+            const uint32_t cg_id = gid_from_isect[batch_start + lane];
+            stage_splat(lds, lane, projected + (size_t)cg_id * BRUSH_PROJECTED_FLOATS);
         }
-        __syncthreads();
-        if (!done) {
-            for (uint32_t t = 0; t < remaining; t++) {
-                const float4 a = lds.a[t];
-                const float4 b = lds.b[t];
-                const float opac = lds.o[t];
-                const float dx = a.x - pcx, dy = a.y - pcy;
-                const float sigma = 0.5f * (a.z * dx * dx + b.x * dy * dy) + a.w * dx * dy;
+        __syncthreads();  // single wave: orders the LDS writes before the broadcast reads
+        for (uint32_t t = 0; t < remaining; t++) {
+            const float4 a = lds.a[t];
+            const float4 b = lds.b[t];
+            const float opac = lds.o[t];
+            const float dy = a.y - pcy;
+            const float cdy2 = b.x * dy * dy;
+            const float bdy = a.w * dy;
+            const float dx0 = a.x - pcx0;
+#pragma unroll
+            for (uint32_t j = 0; j < kPix; j++) {
+                const float dx = dx0 - (float)j;
+                const float sigma = 0.5f * (a.z * dx * dx + cdy2) + bdy * dx;
                 const float vis = __expf(-sigma);
                 const float alpha = fminf(0.999f, opac * vis);
-                if (sigma >= 0.0f && alpha >= 1.0f / 255.0f) {
-                    const float next_T = T * (1.0f - alpha);
+                if (!done[j] && sigma >= 0.0f && alpha >= 1.0f / 255.0f) {
+                    const float next_T = T[j] * (1.0f - alpha);
                     if (next_T <= 1e-4f) {
-                        done = true;
-                        break;
+                        done[j] = true;  // rasterize.wgsl:88-91: stop without adding this entry
+                    } else {
+                        const float fac = alpha * T[j];
+                        cr[j] += b.y * fac;
+                        cg[j] += b.z * fac;
+                        cb[j] += b.w * fac;
+                        T[j] = next_T;
+                        fin[j] = batch_start + t;
                     }
-                    const float fac = alpha * T;
-                    cr += b.y * fac;
-                    cg += b.z * fac;
-                    cb += b.w * fac;
-                    T = next_T;
-                    final_idx = batch_start + t;
                 }
             }
+            if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
         }
     }
 
-    if (inside) {
-        const size_t pix = (size_t)px + (size_t)py * w;
-        const float a = 1.0f - T;
-        if (RASTER_U32) {
-            // rasterize.wgsl:106-109
-            const uint32_t r8 = (uint32_t)fminf(fmaxf(cr * 255.0f, 0.0f), 255.0f);
-            const uint32_t g8 = (uint32_t)fminf(fmaxf(cg * 255.0f, 0.0f), 255.0f);
-            const uint32_t b8 = (uint32_t)fminf(fmaxf(cb * 255.0f, 0.0f), 255.0f);
-            const uint32_t a8 = (uint32_t)fminf(fmaxf(a * 255.0f, 0.0f), 255.0f);
-            static_cast<uint32_t *>(out_img)[pix] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
-        } else {
-            static_cast<float4 *>(out_img)[pix] = make_float4(cr, cg, cb, a);
-            final_index[pix] = final_idx;
+    if (py < h) {
+#pragma unroll
+        for (uint32_t j = 0; j < kPix; j++) {
+            if (px0 + j < w) {
+                const size_t pix = (size_t)(px0 + j) + (size_t)py * w;
+                const float al = 1.0f - T[j];
+                if (RASTER_U32) {
+                    // rasterize.wgsl:106-109
+                    const uint32_t r8 = (uint32_t)fminf(fmaxf(cr[j] * 255.0f, 0.0f), 255.0f);
+                    const uint32_t g8 = (uint32_t)fminf(fmaxf(cg[j] * 255.0f, 0.0f), 255.0f);
+                    const uint32_t b8 = (uint32_t)fminf(fmaxf(cb[j] * 255.0f, 0.0f), 255.0f);
+                    const uint32_t a8 = (uint32_t)fminf(fmaxf(al * 255.0f, 0.0f), 255.0f);
+                    static_cast<uint32_t *>(out_img)[pix] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+                } else {
+                    static_cast<float4 *>(out_img)[pix] = make_float4(cr[j], cg[j], cb[j], al);
+                    final_index[pix] = fin[j];
+                }
+            }
         }
     }
 }
@@ -117,119 +149,146 @@ __global__ __launch_bounds__(kTileSize) void k_rasterize(uint32_t w, uint32_t h,
 
 constexpr uint32_t kGradComps = 9;  // v_xy(2) v_conic(3) v_rgb(3) v_opac(1)
 
-__global__ __launch_bounds__(kTileSize) void k_rasterize_backward(
-    uint32_t w, uint32_t h, uint32_t tbx, const uint32_t *__restrict__ gid_from_isect,
+// Wave64 sum on the VALU with DPP (no LDS traffic, unlike __shfl_xor = ds_bpermute):
+// inclusive scan inside each row of 16 (row_shr 1/2/4/8), then row_bcast:15 and row_bcast:31
+// carry the row totals up.  The full sum is valid in LANE 63 only.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__global__ __launch_bounds__(kWave) void k_rasterize_backward(
+    uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles, const uint32_t *__restrict__ gid_from_isect,
     const uint32_t *__restrict__ tile_bins, const float *__restrict__ projected,
     const uint32_t *__restrict__ final_index, const float *__restrict__ out_img,
-    const float *__restrict__ v_out, float *__restrict__ v_xy, float *__restrict__ v_conics,
-    float *__restrict__ v_colors) {
+    const float *__restrict__ v_out, float *__restrict__ v_compact) {
     __shared__ SplatLds lds;
     __shared__ uint32_t lds_gid[kBatch];
-    __shared__ float acc[kBatch][kGradComps];
+    __shared__ float acc[kBatch][12];  // 9 used; 48-byte rows keep the b128 stores aligned
 
-    const uint32_t tile_id = blockIdx.x;
+    const uint32_t tile_id = xcd_tile(blockIdx.x, num_tiles);
+    if (tile_id >= num_tiles) return;
     const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
-    if (r1 <= r0) return;  // uniform per workgroup
+    if (r1 <= r0) return;
 
     const uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t px = tile_x * kTileWidth + (tid % kTileWidth);
-    const uint32_t py = tile_y * kTileWidth + (tid / kTileWidth);
-    const bool inside = px < w && py < h;
-    const float pcx = (float)px + 0.5f, pcy = (float)py + 0.5f;
-    const size_t pix = (size_t)px + (size_t)py * w;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t px0 = tile_x * kTileWidth + (lane & 3u) * kPix;
+    const uint32_t py = tile_y * kTileWidth + (lane >> 2);
+    const float pcy = (float)py + 0.5f;
+    const float pcx0 = (float)px0 + 0.5f;
 
-    float T_final = 1.0f;
-    uint32_t final_isect = 0;
-    float4 vo = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (inside) {
-        T_final = 1.0f - out_img[pix * 4 + 3];  // rasterize_backwards.wgsl:163
-        final_isect = final_index[pix];
-        vo = reinterpret_cast<const float4 *>(v_out)[pix];
+    bool inside[kPix];
+    float T[kPix], T_final[kPix], bufr[kPix], bufg[kPix], bufb[kPix];
+    float4 vo[kPix];
+    uint32_t fin[kPix];
+#pragma unroll
+    for (uint32_t j = 0; j < kPix; j++) {
+        inside[j] = px0 + j < w && py < h;
+        T_final[j] = 1.0f;
+        fin[j] = 0;
+        vo[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inside[j]) {
+            const size_t pix = (size_t)(px0 + j) + (size_t)py * w;
+            T_final[j] = 1.0f - out_img[pix * 4 + 3];  // rasterize_backwards.wgsl:163
+            fin[j] = final_index[pix];
+            vo[j] = reinterpret_cast<const float4 *>(v_out)[pix];
+        }
+        T[j] = T_final[j];
+        bufr[j] = bufg[j] = bufb[j] = 0.0f;
     }
-    float T = T_final;
-    float bufr = 0.f, bufg = 0.f, bufb = 0.f;
 
     // Batches walk the list back to front (rasterize_backwards.wgsl:194-208).
     for (uint32_t batch_end = r1; batch_end > r0;) {
         const uint32_t remaining = min(kBatch, batch_end - r0);
-        __syncthreads();  // previous batch fully consumed (LDS splats + acc flushed)
-        if (tid < remaining) {
-            const uint32_t cg_id = gid_from_isect[batch_end - 1u - tid];
-            lds_gid[tid] = cg_id;
-            stage_splat(lds, tid, projected + (size_t)cg_id * BRUSH_PROJECTED_FLOATS);
+        __syncthreads();  // previous batch fully flushed
+        if (lane < remaining) {
+            const uint32_t cg_id = gid_from_isect[batch_end - 1u - lane];
+            lds_gid[lane] = cg_id;
+            stage_splat(lds, lane, projected + (size_t)cg_id * BRUSH_PROJECTED_FLOATS);
         }
-        for (uint32_t i = tid; i < kBatch * kGradComps; i += kTileSize) (&acc[0][0])[i] = 0.0f;
+        {
+            float4 *row = reinterpret_cast<float4 *>(&acc[lane][0]);
+            row[0] = row[1] = row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         __syncthreads();
 
         for (uint32_t t = 0; t < remaining; t++) {
             const uint32_t isect_id = batch_end - 1u - t;
+            const float4 a = lds.a[t];
+            const float4 b = lds.b[t];
+            const float opac = lds.o[t];
+            const float dy = a.y - pcy;
+            const float cdy2 = b.x * dy * dy;
+            const float bdy = a.w * dy;
+            const float cdy = b.x * dy;
+            const float dx0 = a.x - pcx0;
             float g[kGradComps];
 #pragma unroll
             for (uint32_t k = 0; k < kGradComps; k++) g[k] = 0.0f;
-            bool active = false;
-            if (inside && isect_id <= final_isect) {
-                const float4 a = lds.a[t];
-                const float4 b = lds.b[t];
-                const float opac = lds.o[t];
-                const float dx = a.x - pcx, dy = a.y - pcy;
-                const float sigma = 0.5f * (a.z * dx * dx + b.x * dy * dy) + a.w * dx * dy;
+            bool any = false;
+#pragma unroll
+            for (uint32_t j = 0; j < kPix; j++) {
+                const float dx = dx0 - (float)j;
+                const float adx = a.z * dx;
+                const float sigma = 0.5f * (adx * dx + cdy2) + bdy * dx;
                 const float vis = __expf(-sigma);
                 const float alpha = fminf(0.99f, opac * vis);  // 0.99 here (rasterize_backwards.wgsl:239)
-                if (sigma >= 0.0f && alpha >= 1.0f / 255.0f) {
-                    active = true;
-                    const float ra = 1.0f / (1.0f - alpha);
-                    T *= ra;
-                    const float fac = alpha * T;
-                    float v_alpha = (b.y * T - bufr * ra) * vo.x + (b.z * T - bufg * ra) * vo.y +
-                                    (b.w * T - bufb * ra) * vo.z;
-                    v_alpha += T_final * ra * vo.w;
-                    bufr += b.y * fac;
-                    bufg += b.z * fac;
-                    bufb += b.w * fac;
+                if (inside[j] && isect_id <= fin[j] && sigma >= 0.0f && alpha >= 1.0f / 255.0f) {
+                    any = true;
+                    // v_rcp_f32 (1 ulp) + one Newton step: the T *= ra chain runs over the whole
+                    // list, so the reciprocal is refined to ~0.5 ulp for 2 extra FMAs.
+                    const float om = 1.0f - alpha;
+                    float ra = __builtin_amdgcn_rcpf(om);
+                    ra = __builtin_fmaf(__builtin_fmaf(-om, ra, 1.0f), ra, ra);
+                    T[j] *= ra;
+                    const float fac = alpha * T[j];
+                    float v_alpha = (b.y * T[j] - bufr[j] * ra) * vo[j].x + (b.z * T[j] - bufg[j] * ra) * vo[j].y +
+                                    (b.w * T[j] - bufb[j] * ra) * vo[j].z;
+                    v_alpha += T_final[j] * ra * vo[j].w;
+                    bufr[j] += b.y * fac;
+                    bufg[j] += b.z * fac;
+                    bufb[j] += b.w * fac;
                     const float v_sigma = -opac * vis * v_alpha;
-                    g[0] = v_sigma * (a.z * dx + a.w * dy);
-                    g[1] = v_sigma * (a.w * dx + b.x * dy);
-                    g[2] = 0.5f * v_sigma * dx * dx;
-                    g[3] = v_sigma * dx * dy;
-                    g[4] = 0.5f * v_sigma * dy * dy;
-                    g[5] = fac * vo.x;
-                    g[6] = fac * vo.y;
-                    g[7] = fac * vo.z;
-                    g[8] = vis * v_alpha;
+                    g[0] += v_sigma * (adx + bdy);
+                    g[1] += v_sigma * (a.w * dx + cdy);
+                    g[2] += 0.5f * v_sigma * dx * dx;
+                    g[3] += v_sigma * dx * dy;
+                    g[4] += 0.5f * v_sigma * dy * dy;
+                    g[5] += fac * vo[j].x;
+                    g[6] += fac * vo[j].y;
+                    g[7] += fac * vo[j].z;
+                    g[8] += vis * v_alpha;
                 }
             }
-            if (__ballot(active) != 0ull) {  // wave-uniform
+            if (__ballot(any) != 0ull) {  // wave-uniform
 #pragma unroll
-                for (uint32_t k = 0; k < kGradComps; k++) g[k] = wave_sum(g[k]);
-                if (lane_id() == 0) {
-#pragma unroll
-                    for (uint32_t k = 0; k < kGradComps; k++) atomicAdd(&acc[t][k], g[k]);
+                for (uint32_t k = 0; k < kGradComps; k++) g[k] = wave_sum_lane63(g[k]);
+                if (lane == 63) {
+                    float4 *row = reinterpret_cast<float4 *>(&acc[t][0]);
+                    row[0] = make_float4(g[0], g[1], g[2], g[3]);
+                    row[1] = make_float4(g[4], g[5], g[6], g[7]);
+                    acc[t][8] = g[8];
                 }
             }
         }
         __syncthreads();
-        // Flush: one hardware float atomic per (tile, splat, component).
-        if (tid < remaining) {
-            const uint32_t cg_id = lds_gid[tid];
-            float s[kGradComps];
-            bool any = false;
-#pragma unroll
-            for (uint32_t k = 0; k < kGradComps; k++) {
-                s[k] = acc[tid][k];
-                any |= s[k] != 0.0f;
-            }
-            if (any) {
-                unsafeAtomicAdd(&v_xy[(size_t)cg_id * 2 + 0], s[0]);
-                unsafeAtomicAdd(&v_xy[(size_t)cg_id * 2 + 1], s[1]);
-                unsafeAtomicAdd(&v_conics[(size_t)cg_id * 3 + 0], s[2]);
-                unsafeAtomicAdd(&v_conics[(size_t)cg_id * 3 + 1], s[3]);
-                unsafeAtomicAdd(&v_conics[(size_t)cg_id * 3 + 2], s[4]);
-                unsafeAtomicAdd(&v_colors[(size_t)cg_id * 4 + 0], s[5]);
-                unsafeAtomicAdd(&v_colors[(size_t)cg_id * 4 + 1], s[6]);
-                unsafeAtomicAdd(&v_colors[(size_t)cg_id * 4 + 2], s[7]);
-                unsafeAtomicAdd(&v_colors[(size_t)cg_id * 4 + 3], s[8]);
-            }
+        // Flush: one hardware float atomic per (tile, splat, component); consecutive lanes take
+        // consecutive components of one splat (MI355X_MICROARCH.md, global float atomics).
+        for (uint32_t f = lane; f < remaining * kGradComps; f += kWave) {
+            const uint32_t t = f / kGradComps, k = f - t * kGradComps;
+            const float v = acc[t][k];
+            if (v != 0.0f) unsafeAtomicAdd(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], v);
         }
         batch_end -= remaining;
     }
@@ -243,12 +302,13 @@ hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                             hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
+    const dim3 grid(ceil_div(tiles, 8u) * 8u), block(kWave);
     if (raster_u32) {
-        hipLaunchKernelGGL(k_rasterize<true>, dim3(tiles), dim3(kTileSize), 0, s, w, h, tbx, compact_gid_from_isect,
-                           tile_bins, projected, out_img, final_index);
+        hipLaunchKernelGGL(k_rasterize<true>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins,
+                           projected, out_img, final_index);
     } else {
-        hipLaunchKernelGGL(k_rasterize<false>, dim3(tiles), dim3(kTileSize), 0, s, w, h, tbx,
-                           compact_gid_from_isect, tile_bins, projected, out_img, final_index);
+        hipLaunchKernelGGL(k_rasterize<false>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins,
+                           projected, out_img, final_index);
     }
     return hipGetLastError();
 }
@@ -256,12 +316,13 @@ hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
 hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                                      const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
                                      const float *projected, const uint32_t *final_index,
-                                     const float *out_img, const float *v_out, float *v_xy_local,
-                                     float *v_conics, float *v_colors, hipStream_t s) {
+                                     const float *out_img, const float *v_out, float *v_compact,
+                                     hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rasterize_backward, dim3(tiles), dim3(kTileSize), 0, s, w, h, tbx, compact_gid_from_isect,
-                       tile_bins, projected, final_index, out_img, v_out, v_xy_local, v_conics, v_colors);
+    const dim3 grid(ceil_div(tiles, 8u) * 8u), block(kWave);
+    hipLaunchKernelGGL(k_rasterize_backward, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins,
+                       projected, final_index, out_img, v_out, v_compact);
     return hipGetLastError();
 }
 

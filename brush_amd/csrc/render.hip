@@ -80,9 +80,7 @@ FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap) {
 }
 
 struct BwdWs {
-    float *v_xy_local;  // [N,2] compact order
-    float *v_conics;    // [N,3]
-    float *v_colors;    // [N,4]
+    float *v_compact;  // [N, kCompactStride] compact-order gradient rows (first V used)
     size_t bytes;
 };
 
@@ -90,9 +88,7 @@ BwdWs carve_bwd(void *ws, uint32_t n) {
     BwdWs b;
     Carver c(ws);
     const size_t nn = n ? n : 1;
-    b.v_xy_local = c.take<float>(nn * 2);
-    b.v_conics = c.take<float>(nn * 3);
-    b.v_colors = c.take<float>(nn * 4);
+    b.v_compact = c.take<float>(nn * kCompactStride);
     b.bytes = c.bytes();
     return b;
 }
@@ -242,17 +238,16 @@ extern "C" int brush_render_backward(const BrushUniforms *h_uniforms, const Brus
 
     mark_bwd(s, 0);
     // compact-order accumulators are atomically added to: zero the first V rows (render.rs:505-507)
-    BRUSH_HIP_CHECK(launch_zero_compact_grads(aux.num_visible, n, ws.v_xy_local, ws.v_conics, ws.v_colors, s));
+    BRUSH_HIP_CHECK(launch_zero_compact_grads(aux.num_visible, n, ws.v_compact, s));
     mark_bwd(s, 1);
     // RasterizeBackwards (render.rs:515-532)
     BRUSH_HIP_CHECK(launch_rasterize_backward(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
                                               aux.projected_splats, aux.final_index, out_img, v_out,
-                                              ws.v_xy_local, ws.v_conics, ws.v_colors, s));
+                                              ws.v_compact, s));
     mark_bwd(s, 2);
     // GatherGrads + ProjectBackwards fused, dense outputs written once (render.rs:534-594)
     BRUSH_HIP_CHECK(launch_project_backward(vp, means, log_scales, quats, raw_opacity, aux.compact_from_global_gid,
-                                            ws.v_xy_local, ws.v_conics, ws.v_colors, v_means, v_xy, v_scales,
-                                            v_quats, v_sh, v_opac, s));
+                                            ws.v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac, s));
     mark_bwd(s, 3);
     return BRUSH_OK;
 }
