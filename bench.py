@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=20, help="extra steps with stage events (untimed)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="enqueue every launch from the host instead of replaying one captured hipGraph per step")
     return ap.parse_args()
 
 
@@ -113,10 +115,33 @@ def main():
     block = torch.empty(total, dtype=torch.float32, device=dev)
     param_floats = layout["v_sh"][0] + layout["v_sh"][1]  # [means|scales|quats|opac|sh] contiguous prefix
 
-    def step():
+    def fwd_bwd():
         out, aux, u = R._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"],
                                       False, cap)
         R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], C, out, v_out, block)
+        return aux
+
+    # The op never syncs, allocates or reads a count back, so one fwd+bwd is a capturable launch
+    # sequence: replaying it as a hipGraph removes the ~3.5 us/launch host enqueue cost
+    # (DESIGN.md "launch floor").  The all-reduce stays outside the graph.
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fwd_bwd()  # warm allocator + code objects before capture
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_aux = fwd_bwd()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            aux = graph_aux
+        else:
+            aux = fwd_bwd()
         if world > 1:
             dist.all_reduce(block[:param_floats])  # dense gradient block, sum over views
         return aux
@@ -150,7 +175,7 @@ def main():
     with StageProfiler() as prof:
         acc = None
         for _ in range(max(1, args.profile_steps)):
-            step()
+            fwd_bwd()  # eager: events cannot be recorded inside a replayed graph
             ms = prof.read_ms()
             acc = ms if acc is None else {k: acc[k] + ms[k] for k in ms}
         stage_ms = {k: v / max(1, args.profile_steps) for k, v in acc.items()}
@@ -199,6 +224,7 @@ def main():
             "config": {"workload": f"S1: {n} splats @{w}x{h}, SH degree {deg}, seed 4, mean_mult {args.mean_mult}, "
                                    f"fwd+bwd per view", "views_per_step": n_gpus,
                        "parallelism": f"view-sharded dp{n_gpus}" if n_gpus > 1 else "single GPU",
+                       "launch": "eager" if graph is None else "hipGraph replay of one fwd+bwd",
                        "num_visible": V, "num_intersections": I, "max_intersects": aux.max_intersects,
                        "overflow": overflow},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "whole_path": whole_path,

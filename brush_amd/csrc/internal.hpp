@@ -7,12 +7,11 @@ namespace brush {
 struct ViewParams;
 
 // project.hip
-hipError_t launch_init(const BrushUniforms &u, const BrushAux &aux, uint32_t num_tiles, hipStream_t s);
 size_t cull_block_count(uint32_t n);
-hipError_t launch_project_cull(const ViewParams &vp, const float *means, const float *log_scales,
-                               const float *quats, uint32_t *key_all, uint32_t *compact_from_global,
-                               uint32_t *block_counts, uint32_t *num_visible, uint32_t *uniforms_buffer,
-                               uint32_t *keys, uint32_t *gids, hipStream_t s);
+hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, const BrushAux &aux,
+                               uint32_t num_tiles, const float *means, const float *log_scales,
+                               const float *quats, uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
+                               uint32_t *gids, hipStream_t s);
 hipError_t launch_project_visible(const ViewParams &vp, const float *means, const float *log_scales,
                                   const float *quats, const float *sh, const float *raw_opac,
                                   const uint32_t *num_visible, uint32_t *global_from_compact,

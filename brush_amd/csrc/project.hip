@@ -29,71 +29,114 @@ namespace brush {
 namespace {
 
 constexpr uint32_t kThreads = 256;
-// Bboxes above this many tiles are walked by the whole wave (64 tiles per step) instead of by
-// their owning lane: the nearest splats cover thousands of tiles and sit in adjacent lanes.
-constexpr uint32_t kCoopArea = 32;
+// Bboxes above this many tiles are walked by the whole workgroup (256 tiles per step) instead of
+// by their owning lane: the nearest splats cover thousands of tiles.
+constexpr uint32_t kCoopArea = 8;
 
 // Compact ids are in depth order, so the nearest (largest-footprint) splats are neighbours.
 // To keep them out of one wave, lane t of block b takes the 4 consecutive ids of group
 // (t/4)*gridDim + b: neighbours in depth order land in different workgroups, while each
 // group's 4 x 36 B records still form one contiguous 144-byte run.
 __device__ __forceinline__ uint32_t interleaved_id(uint32_t round, uint32_t tid, uint32_t bid, uint32_t nblocks) {
-    return round * (nblocks * kThreads) + (((tid >> 2) * nblocks + bid) << 2) + (tid & 3u);
+    return round * (nblocks * kThreads) + tid * nblocks + bid;
 }
 
-__device__ __forceinline__ float bcast(float v, int src) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-__device__ __forceinline__ uint32_t bcast(uint32_t v, int src) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+// Descriptor of a splat whose bbox is walked by the whole workgroup.
+struct BigSplat {
+    float q[3];
+    float xy[2];
+    uint32_t any;
+    uint32_t b0, b1, bw, area;
+    uint32_t c, isect;
+};
+
+struct WalkShared {
+    BigSplat big[kThreads];
+    uint32_t count[kThreads];
+    uint32_t wave_cnt[kThreads / kWave];
+    uint32_t nbig;
+};
+
+__device__ __forceinline__ bool big_hit(const BigSplat &d, uint32_t i, uint32_t &tx, uint32_t &ty) {
+    TileTest st;
+    st.q[0] = d.q[0];
+    st.q[1] = d.q[1];
+    st.q[2] = d.q[2];
+    st.any = d.any != 0;
+    tx = d.b0 + i % d.bw;
+    ty = d.b1 + i / d.bw;
+    return can_be_visible(st, tx, ty, d.xy);
 }
 
-// Number of bbox tiles that pass can_be_visible for this lane's splat.  Must be called by all
-// 64 lanes of the wave (inactive lanes pass active = false).
-__device__ __forceinline__ uint32_t count_tiles(bool active, const uint32_t bb[4], const TileTest &tt,
-                                                const float xy[2]) {
+// Queue this lane's splat for the workgroup walk; returns its slot.  Called between two
+// __syncthreads() that bracket the zeroing of sh.nbig and the reading of the list.
+__device__ __forceinline__ uint32_t push_big(WalkShared &sh, const uint32_t bb[4], const TileTest &tt,
+                                             const float xy[2], uint32_t area, uint32_t c, uint32_t isect) {
+    const uint32_t slot = atomicAdd(&sh.nbig, 1u);
+    BigSplat d;
+    d.q[0] = tt.q[0];
+    d.q[1] = tt.q[1];
+    d.q[2] = tt.q[2];
+    d.xy[0] = xy[0];
+    d.xy[1] = xy[1];
+    d.any = tt.any ? 1u : 0u;
+    d.b0 = bb[0];
+    d.b1 = bb[1];
+    d.bw = bb[2] - bb[0];
+    d.area = area;
+    d.c = c;
+    d.isect = isect;
+    sh.big[slot] = d;
+    sh.count[slot] = 0;
+    return slot;
+}
+
+// Number of bbox tiles that pass can_be_visible for this lane's splat.  Must be called by every
+// thread of the workgroup (inactive lanes pass active = false).  Small bboxes are walked by their
+// lane; bboxes above kCoopArea tiles are walked by all 256 threads, 256 tiles per step.
+__device__ __forceinline__ uint32_t count_tiles(WalkShared &sh, bool active, const uint32_t bb[4],
+                                                const TileTest &tt, const float xy[2]) {
     const uint32_t bw = bb[2] - bb[0], bh = bb[3] - bb[1];
     const uint32_t area = active ? bw * bh : 0u;
     const bool big = area > kCoopArea;
-    uint32_t cnt = 0;
+    if (threadIdx.x == 0) sh.nbig = 0;
+    __syncthreads();
+    uint32_t cnt = 0, slot = 0;
     if (active && !big) {
         for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
             for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
                 if (can_be_visible(tt, tx, ty, xy)) cnt++;
     }
-    uint64_t m = __ballot(big);
-    const uint32_t lane = lane_id();
-    while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        TileTest st;
-        st.q[0] = bcast(tt.q[0], src);
-        st.q[1] = bcast(tt.q[1], src);
-        st.q[2] = bcast(tt.q[2], src);
-        st.any = bcast((uint32_t)tt.any, src) != 0;
-        const float sxy[2] = {bcast(xy[0], src), bcast(xy[1], src)};
-        const uint32_t sb0 = bcast(bb[0], src), sb1 = bcast(bb[1], src);
-        const uint32_t sbw = bcast(bw, src), sarea = bcast(area, src);
-        uint32_t c = 0;
-        for (uint32_t i0 = 0; i0 < sarea; i0 += kWave) {
-            const uint32_t i = i0 + lane;
-            bool hit = false;
-            if (i < sarea) hit = can_be_visible(st, sb0 + i % sbw, sb1 + i / sbw, sxy);
-            c += __popcll(__ballot(hit));
+    if (big) slot = push_big(sh, bb, tt, xy, area, 0u, 0u);
+    __syncthreads();
+    const uint32_t nbig = sh.nbig;
+    for (uint32_t b = 0; b < nbig; b++) {
+        const BigSplat d = sh.big[b];
+        uint32_t local = 0;
+        for (uint32_t i0 = 0; i0 < d.area; i0 += kThreads) {
+            const uint32_t i = i0 + threadIdx.x;
+            uint32_t tx, ty;
+            const bool hit = i < d.area && big_hit(d, i, tx, ty);
+            local += __popcll(__ballot(hit));
         }
-        if ((int)lane == src) cnt = c;
+        if (lane_id() == 0 && local) atomicAdd(&sh.count[b], local);
     }
+    __syncthreads();
+    if (big) cnt = sh.count[slot];
     return cnt;
 }
 
 // Emits (tile id, compact gid) for every passing bbox tile in row-major order starting at
 // `isect`.  Same calling convention as count_tiles.
-__device__ __forceinline__ void emit_tiles(bool active, uint32_t c, uint32_t isect, const uint32_t bb[4],
-                                           const TileTest &tt, const float xy[2], uint32_t tbx, uint32_t cap,
-                                           uint32_t *__restrict__ tile_ids, uint32_t *__restrict__ gids) {
+__device__ __forceinline__ void emit_tiles(WalkShared &sh, bool active, uint32_t c, uint32_t isect,
+                                           const uint32_t bb[4], const TileTest &tt, const float xy[2],
+                                           uint32_t tbx, uint32_t cap, uint32_t *__restrict__ tile_ids,
+                                           uint32_t *__restrict__ gids) {
     const uint32_t bw = bb[2] - bb[0], bh = bb[3] - bb[1];
     const uint32_t area = active ? bw * bh : 0u;
     const bool big = area > kCoopArea;
+    if (threadIdx.x == 0) sh.nbig = 0;
+    __syncthreads();
     if (active && !big) {
         for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
             for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
@@ -103,69 +146,62 @@ __device__ __forceinline__ void emit_tiles(bool active, uint32_t c, uint32_t ise
                     isect++;
                 }
     }
-    uint64_t m = __ballot(big);
-    const uint32_t lane = lane_id();
+    if (big) push_big(sh, bb, tt, xy, area, c, isect);
+    __syncthreads();
+    const uint32_t nbig = sh.nbig;
+    const uint32_t wid = threadIdx.x / kWave;
     const uint64_t lt = lanemask_lt();
-    while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        TileTest st;
-        st.q[0] = bcast(tt.q[0], src);
-        st.q[1] = bcast(tt.q[1], src);
-        st.q[2] = bcast(tt.q[2], src);
-        st.any = bcast((uint32_t)tt.any, src) != 0;
-        const float sxy[2] = {bcast(xy[0], src), bcast(xy[1], src)};
-        const uint32_t sb0 = bcast(bb[0], src), sb1 = bcast(bb[1], src);
-        const uint32_t sbw = bcast(bw, src), sarea = bcast(area, src);
-        const uint32_t sc = bcast(c, src);
-        uint32_t run = bcast(isect, src);
-        for (uint32_t i0 = 0; i0 < sarea; i0 += kWave) {
-            const uint32_t i = i0 + lane;
-            bool hit = false;
+    for (uint32_t b = 0; b < nbig; b++) {
+        const BigSplat d = sh.big[b];
+        uint32_t run = d.isect;
+        for (uint32_t i0 = 0; i0 < d.area; i0 += kThreads) {
+            const uint32_t i = i0 + threadIdx.x;
             uint32_t tx = 0, ty = 0;
-            if (i < sarea) {
-                tx = sb0 + i % sbw;
-                ty = sb1 + i / sbw;
-                hit = can_be_visible(st, tx, ty, sxy);
+            const bool hit = i < d.area && big_hit(d, i, tx, ty);
+            const uint64_t bal = __ballot(hit);
+            if (lane_id() == 0) sh.wave_cnt[wid] = __popcll(bal);
+            __syncthreads();
+            uint32_t pos = run + __popcll(bal & lt);
+            uint32_t total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kThreads / kWave; w++) {
+                const uint32_t wc = sh.wave_cnt[w];
+                if (w < wid) pos += wc;
+                total += wc;
             }
-            const uint64_t b = __ballot(hit);
-            const uint32_t pos = run + __popcll(b & lt);
             if (hit && pos < cap) {
                 tile_ids[pos] = tx + ty * tbx;
-                gids[pos] = sc;
+                gids[pos] = d.c;
             }
-            run += __popcll(b);
+            run += total;
+            __syncthreads();
         }
     }
 }
 
-// ---- init: uniforms buffer, counters, tile bins -----------------------------------------
-__global__ __launch_bounds__(kThreads) void k_init(BrushUniforms u, uint32_t *__restrict__ uniforms_buffer,
-                                                   uint32_t *__restrict__ num_intersections,
-                                                   uint32_t *__restrict__ overflow,
-                                                   uint32_t *__restrict__ tile_bins, uint32_t num_bin_words) {
-    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gtid < kUniformWords) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&u);
-        uniforms_buffer[gtid] = w[gtid];
-    }
-    if (gtid == 0) {
-        *num_intersections = 0;
-        *overflow = 0;
-    }
-    for (uint32_t i = gtid; i < num_bin_words; i += gridDim.x * blockDim.x) tile_bins[i] = 0;  // render.rs:241-244
-}
-
 // ---- ProjectSplats: cull + depth key ------------------------------------------------------
-// project_forward.wgsl:15-68.  One splat per lane; 40 B read, 8 B written per splat.
-__global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, const float *__restrict__ means,
+// project_forward.wgsl:15-68.  One splat per lane; 40 B read, 8 B written per splat.  Being the
+// first launch of the forward pass it also publishes the uniforms buffer and clears the counters
+// and tile_bins (render.rs:102-116,241-244) so that no separate init launch is needed.
+__global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushUniforms u,
+                                                           const float *__restrict__ means,
                                                            const float *__restrict__ log_scales,
                                                            const float *__restrict__ quats,
                                                            uint32_t *__restrict__ key_all,
                                                            uint32_t *__restrict__ compact_from_global,
-                                                           uint32_t *__restrict__ block_counts) {
+                                                           uint32_t *__restrict__ block_counts,
+                                                           uint32_t *__restrict__ uniforms_buffer,
+                                                           uint32_t *__restrict__ num_intersections,
+                                                           uint32_t *__restrict__ overflow,
+                                                           uint32_t *__restrict__ tile_bins, uint32_t num_bin_words) {
     __shared__ uint32_t wave_cnt[kThreads / kWave];
     const uint32_t g = blockIdx.x * kThreads + threadIdx.x;
+    if (g < kUniformWords) uniforms_buffer[g] = reinterpret_cast<const uint32_t *>(&u)[g];
+    if (g == 0) {
+        *num_intersections = 0;
+        *overflow = 0;
+    }
+    for (uint32_t i = g; i < num_bin_words; i += gridDim.x * kThreads) tile_bins[i] = 0;
     bool visible = false;
     float depth = 0.0f;
     if (g < vp.total_splats) {
@@ -258,14 +294,17 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
     const float *__restrict__ quats, const float *__restrict__ sh_coeffs, const float *__restrict__ raw_opac,
     const uint32_t *__restrict__ num_visible, uint32_t *__restrict__ global_from_compact,
     uint32_t *__restrict__ compact_from_global, float *__restrict__ projected, uint32_t *__restrict__ tiles_hit) {
+    __shared__ WalkShared sh;
     const uint32_t V = *num_visible;
     const uint32_t n = vp.total_splats;
     const uint32_t ncoef = (vp.sh_degree + 1) * (vp.sh_degree + 1);
-    // Block-uniform trip count: every lane of a wave reaches count_tiles() together.
-    const uint32_t rounds = (n + gridDim.x * kThreads - 1) / (gridDim.x * kThreads);
+    // Block-uniform trip count: every thread of the workgroup reaches count_tiles() together.
+    // Tail of global_from_compact_gid (never written by the sort) := 0, coalesced.
+    for (uint32_t i = V + blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+        global_from_compact[i] = 0;
+    const uint32_t rounds = (V + gridDim.x * kThreads - 1) / (gridDim.x * kThreads);
     for (uint32_t round = 0; round < rounds; round++) {
         const uint32_t c = interleaved_id(round, threadIdx.x, blockIdx.x, gridDim.x);
-        if (c < n && c >= V) global_from_compact[c] = 0;
         const bool active = c < V;
         float xy[2] = {0.f, 0.f}, conic[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
         float opac = 0.f;
@@ -326,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
             get_tile_bbox(xy, radius, vp.tile_bounds, bb);
             tt = make_tile_test(conic, opac);
         }
-        const uint32_t area = count_tiles(active, bb, tt, xy);
+        const uint32_t area = count_tiles(sh, active, bb, tt, xy);
         if (active) {
             float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
             p[0] = xy[0];
@@ -350,6 +389,7 @@ __global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, cons
                                                              const uint32_t *__restrict__ num_visible,
                                                              uint32_t cap, uint32_t *__restrict__ tile_ids,
                                                              uint32_t *__restrict__ gids) {
+    __shared__ WalkShared sh;
     const uint32_t V = *num_visible;
     const uint32_t rounds = (V + gridDim.x * kThreads - 1) / (gridDim.x * kThreads);
     for (uint32_t round = 0; round < rounds; round++) {
@@ -372,7 +412,7 @@ __global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, cons
             tt = make_tile_test(conic, opac);
             isect = c > 0 ? cum_tiles_hit[c - 1] : 0u;
         }
-        emit_tiles(active, c, isect, bb, tt, xy, vp.tile_bounds[0], cap, tile_ids, gids);
+        emit_tiles(sh, active, c, isect, bb, tt, xy, vp.tile_bounds[0], cap, tile_ids, gids);
     }
 }
 
@@ -398,25 +438,26 @@ __global__ __launch_bounds__(kThreads) void k_tile_bin_edges(const uint32_t *__r
 }
 
 uint32_t stride_grid(uint32_t work_items) { return max(1u, min(ceil_div(work_items, kThreads), 2048u)); }
+// The two tile-walk kernels hold ~100 VGPRs (4 workgroups per CU): a 1024-block grid is fully
+// resident on 256 CUs, so no workgroup waits for a slot behind a long tile walk.
+uint32_t walk_grid(uint32_t work_items) { return max(1u, min(ceil_div(work_items, kThreads), 1024u)); }
 
 }  // namespace
 
-hipError_t launch_init(const BrushUniforms &u, const BrushAux &aux, uint32_t num_tiles, hipStream_t s) {
-    hipLaunchKernelGGL(k_init, dim3(stride_grid(num_tiles * 2)), dim3(kThreads), 0, s, u, aux.uniforms_buffer,
-                       aux.num_intersections, aux.overflow, aux.tile_bins, num_tiles * 2);
-    return hipGetLastError();
-}
-
 size_t cull_block_count(uint32_t n) { return ceil_div(n ? n : 1, kThreads); }
 
-hipError_t launch_project_cull(const ViewParams &vp, const float *means, const float *log_scales,
-                               const float *quats, uint32_t *key_all, uint32_t *compact_from_global,
-                               uint32_t *block_counts, uint32_t *num_visible, uint32_t *uniforms_buffer,
-                               uint32_t *keys, uint32_t *gids, hipStream_t s) {
+hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, const BrushAux &aux,
+                               uint32_t num_tiles, const float *means, const float *log_scales,
+                               const float *quats, uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
+                               uint32_t *gids, hipStream_t s) {
     const uint32_t n = vp.total_splats;
     const uint32_t blocks = (uint32_t)cull_block_count(n);
-    hipLaunchKernelGGL(k_project_cull, dim3(blocks), dim3(kThreads), 0, s, vp, means, log_scales, quats, key_all,
-                       compact_from_global, block_counts);
+    uint32_t *compact_from_global = aux.compact_from_global_gid;
+    uint32_t *num_visible = aux.num_visible;
+    uint32_t *uniforms_buffer = aux.uniforms_buffer;
+    hipLaunchKernelGGL(k_project_cull, dim3(blocks), dim3(kThreads), 0, s, vp, u, means, log_scales, quats, key_all,
+                       compact_from_global, block_counts, uniforms_buffer, aux.num_intersections, aux.overflow,
+                       aux.tile_bins, num_tiles * 2);
     hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, s, block_counts, blocks, num_visible,
                        uniforms_buffer);
     hipLaunchKernelGGL(k_compact, dim3(blocks), dim3(kThreads), 0, s, n, key_all, block_counts, keys, gids);
@@ -428,7 +469,7 @@ hipError_t launch_project_visible(const ViewParams &vp, const float *means, cons
                                   const uint32_t *num_visible, uint32_t *global_from_compact,
                                   uint32_t *compact_from_global, float *projected, uint32_t *tiles_hit,
                                   hipStream_t s) {
-    hipLaunchKernelGGL(k_project_visible, dim3(stride_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, means,
+    hipLaunchKernelGGL(k_project_visible, dim3(walk_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, means,
                        log_scales, quats, sh, raw_opac, num_visible, global_from_compact, compact_from_global,
                        projected, tiles_hit);
     return hipGetLastError();
@@ -437,7 +478,7 @@ hipError_t launch_project_visible(const ViewParams &vp, const float *means, cons
 hipError_t launch_map_intersects(const ViewParams &vp, const float *projected, const uint32_t *cum_tiles_hit,
                                  const uint32_t *num_visible, uint32_t cap, uint32_t *tile_ids, uint32_t *gids,
                                  hipStream_t s) {
-    hipLaunchKernelGGL(k_map_intersects, dim3(stride_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, projected,
+    hipLaunchKernelGGL(k_map_intersects, dim3(walk_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, projected,
                        cum_tiles_hit, num_visible, cap, tile_ids, gids);
     return hipGetLastError();
 }

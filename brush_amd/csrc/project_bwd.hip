@@ -12,6 +12,12 @@
 // Traffic per splat: 4 B (map) + 40 B params + 36 B compact grads (visible only) read,
 // 52 + 12*C B written.  Roofline: HBM.
 //
+// Store shape: a lane's v_sh row is 12*C contiguous bytes, so per-lane stores would touch 64
+// different rows per instruction.  Each wave instead parks its 64 rows in a private LDS buffer
+// (odd row stride, so the column writes are bank-conflict free) and copies the block out as contiguous
+// 16-byte-per-lane stores: one full KiB per wave-instruction.  v_means / v_scales (12 B rows) go
+// through the same buffer; v_quats / v_xy / v_opac are already lane-contiguous.
+//
 // Compiled with -ffp-contract=off (same expression trees as the forward projection).
 #include "internal.hpp"
 #include "splat_math.hpp"
@@ -71,10 +77,20 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     float *__restrict__ v_means,
     float *__restrict__ v_xy, float *__restrict__ v_scales, float *__restrict__ v_quats,
     float *__restrict__ v_sh, float *__restrict__ v_opac) {
-    const uint32_t g = blockIdx.x * kThreads + threadIdx.x;
-    if (g >= vp.total_splats) return;
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
-    const uint32_t c = compact_from_global[g];
+    constexpr uint32_t kRow = ncoef * 3;                 // floats per v_sh row
+    constexpr uint32_t kRowPad = kRow | 1u;              // odd LDS row stride: conflict-free column access
+    constexpr uint32_t kStageFloats = (kWave * kRowPad > 512u ? kWave * kRowPad : 512u);
+    __shared__ float stage_all[kThreads / kWave][kStageFloats];
+    const uint32_t wv = threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    float *stage = stage_all[wv];
+    const uint32_t n = vp.total_splats;
+    const uint32_t g0 = blockIdx.x * kThreads + wv * kWave;  // first splat of this wave
+    if (g0 >= n) return;                                      // wave-uniform
+    const uint32_t g = g0 + lane;
+    const bool in_range = g < n;
+    const uint32_t c = in_range ? compact_from_global[g] : kInvalid;
 
     float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_quat[4] = {0.f, 0.f, 0.f, 0.f};
     float o_xy[2] = {0.f, 0.f}, o_opac = 0.f;
@@ -188,21 +204,62 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
         quat_to_rotmat_vjp(quat, v_R, o_quat);
     }
 
-    v_means[(size_t)g * 3 + 0] = o_mean[0];
-    v_means[(size_t)g * 3 + 1] = o_mean[1];
-    v_means[(size_t)g * 3 + 2] = o_mean[2];
-    v_scales[(size_t)g * 3 + 0] = o_scale[0];
-    v_scales[(size_t)g * 3 + 1] = o_scale[1];
-    v_scales[(size_t)g * 3 + 2] = o_scale[2];
-    reinterpret_cast<float4 *>(v_quats)[g] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
-    reinterpret_cast<float2 *>(v_xy)[g] = make_float2(o_xy[0], o_xy[1]);
-    v_opac[g] = o_opac;
-    float *vs = v_sh + (size_t)g * ncoef * 3;
+    const uint32_t rows = min(kWave, n - g0);  // rows this wave owns (64 except at the tail)
+    if (in_range) {
+        reinterpret_cast<float4 *>(v_quats)[g] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
+        reinterpret_cast<float2 *>(v_xy)[g] = make_float2(o_xy[0], o_xy[1]);
+        v_opac[g] = o_opac;
+    }
+
+    // Copies `rows` rows of ROWF floats (row r at stage[r*STRIDE]) to dst, contiguous across lanes.
+    auto copy_out = [&](float *__restrict__ dst, uint32_t rowf, uint32_t stride) {
+        const uint32_t total = rows * rowf;  // floats; dst is 16-B aligned when g0*rowf % 4 == 0
+        if ((rowf & 3u) == 0 || rows == kWave) {
+            // float4 path: rowf*64 is a multiple of 4 and the wave's base offset is 16-B aligned
+            for (uint32_t j = lane * 4; j < total; j += kWave * 4) {
+                if (j + 4 <= total) {
+                    float4 v;
+                    float *e = reinterpret_cast<float *>(&v);
 #pragma unroll
-    for (uint32_t k = 0; k < ncoef; k++) {
-        vs[k * 3 + 0] = Y[k] * vcol[0];
-        vs[k * 3 + 1] = Y[k] * vcol[1];
-        vs[k * 3 + 2] = Y[k] * vcol[2];
+                    for (uint32_t i = 0; i < 4; i++) {
+                        const uint32_t f = j + i;
+                        e[i] = stage[(f / rowf) * stride + (f % rowf)];
+                    }
+                    *reinterpret_cast<float4 *>(dst + j) = v;
+                } else {
+                    for (uint32_t f = j; f < total; f++) dst[f] = stage[(f / rowf) * stride + (f % rowf)];
+                }
+            }
+        } else {
+            for (uint32_t f = lane; f < total; f += kWave) dst[f] = stage[(f / rowf) * stride + (f % rowf)];
+        }
+    };
+
+    // v_sh: row = Y[k] * v_rgb
+    {
+        float *row = stage + lane * kRowPad;
+#pragma unroll
+        for (uint32_t k = 0; k < ncoef; k++) {
+            row[k * 3 + 0] = Y[k] * vcol[0];
+            row[k * 3 + 1] = Y[k] * vcol[1];
+            row[k * 3 + 2] = Y[k] * vcol[2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        copy_out(v_sh + (size_t)g0 * kRow, kRow, kRowPad);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // v_means, v_scales: 3 floats per row
+    {
+        stage[lane * 4 + 0] = o_mean[0];
+        stage[lane * 4 + 1] = o_mean[1];
+        stage[lane * 4 + 2] = o_mean[2];
+        stage[256 + lane * 4 + 0] = o_scale[0];
+        stage[256 + lane * 4 + 1] = o_scale[1];
+        stage[256 + lane * 4 + 2] = o_scale[2];
+        __builtin_amdgcn_wave_barrier();
+        copy_out(v_means + (size_t)g0 * 3, 3, 4);
+        stage += 256;
+        copy_out(v_scales + (size_t)g0 * 3, 3, 4);
     }
 }
 

@@ -12,7 +12,10 @@
 //                 lowest peer lane bumps the wave's private LDS counter; 4-wave combine; the
 //                 256 digit bases come from a block scan of totals[]; scatter.
 // The element count stays on the device (*d_n): grids are sized for max_n and surplus blocks
-// exit on their first instruction.  Stability: tiles, wave chunks, rounds and lanes are all
+// exit on their first instruction.  The tile size is also chosen ON THE DEVICE from *d_n
+// (1, 2, 4, 8 or 16 keys per lane, the smallest that keeps the tile count <= 1024): a 100 k-key
+// sort then spreads over ~400 workgroups instead of 25, and an 8 M-key sort still uses 4096-key
+// tiles.  All three kernels derive the same value, so the partition is consistent.  Stability: tiles, wave chunks, rounds and lanes are all
 // ranked in index order.  Traffic per pass: 4 B/key (upsweep) + 16 B/pair (downsweep).
 // Roofline: HBM.  The pass structure sorts exactly the reference's 4*ceil(bits/4) low bits.
 #include "common.hpp"
@@ -22,9 +25,28 @@ namespace {
 
 constexpr uint32_t kSortThreads = 256;
 constexpr uint32_t kSortWaves = kSortThreads / kWave;
-constexpr uint32_t kSortItems = 16;
-constexpr uint32_t kSortTile = kSortThreads * kSortItems;  // 4096
+constexpr uint32_t kSortMaxItems = 16;
+constexpr uint32_t kSortTargetTiles = 1024;
 constexpr uint32_t kRadix = 256;
+
+// Keys per lane for a sort of n keys: smallest power of two K in [1,16] with n/(256 K) <= 1024.
+__host__ __device__ __forceinline__ uint32_t sort_items(uint32_t n) {
+    uint32_t k = 1;
+    while (k < kSortMaxItems && (uint64_t)kSortThreads * k * kSortTargetTiles < n) k <<= 1;
+    return k;
+}
+// Upper bound of the tile count over every n <= max_n (size of one row of the counts table).
+inline uint32_t sort_max_tiles(uint32_t max_n) {
+    uint32_t best = 1;
+    for (uint32_t k = 1; k <= kSortMaxItems; k <<= 1) {
+        // largest n that still selects k
+        uint64_t hi = (k == kSortMaxItems) ? max_n : (uint64_t)kSortThreads * k * kSortTargetTiles;
+        if (hi > max_n) hi = max_n;
+        const uint32_t tiles = (uint32_t)((hi + (uint64_t)kSortThreads * k - 1) / ((uint64_t)kSortThreads * k));
+        if (tiles > best) best = tiles;
+    }
+    return best;
+}
 
 __global__ __launch_bounds__(kSortThreads) void k_sort_upsweep(const uint32_t *__restrict__ keys,
                                                               const uint32_t *__restrict__ d_n,
@@ -32,15 +54,16 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_upsweep(const uint32_t *_
                                                               uint32_t *__restrict__ counts,
                                                               uint32_t max_tiles) {
     const uint32_t n = min(*d_n, max_n);
+    const uint32_t items = sort_items(n);
+    const uint32_t tile_keys = kSortThreads * items;
     const uint32_t tile = blockIdx.x;
-    if (tile * kSortTile >= n) return;
+    if ((uint64_t)tile * tile_keys >= n) return;
     __shared__ uint32_t hist[kSortWaves][kRadix];
     for (uint32_t i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&hist[0][0])[i] = 0;
     __syncthreads();
     const uint32_t wid = threadIdx.x / kWave;
-    const uint32_t base = tile * kSortTile;
-#pragma unroll
-    for (uint32_t i = 0; i < kSortItems; i++) {
+    const uint32_t base = tile * tile_keys;
+    for (uint32_t i = 0; i < items; i++) {
         const uint32_t idx = base + i * kSortThreads + threadIdx.x;
         if (idx < n) atomicAdd(&hist[wid][(keys[idx] >> shift) & mask], 1u);
     }
@@ -56,7 +79,8 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ counts
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t carry_s;
     const uint32_t n = min(*d_n, max_n);
-    const uint32_t num_tiles = (n + kSortTile - 1) / kSortTile;
+    const uint32_t tile_keys = kSortThreads * sort_items(n);
+    const uint32_t num_tiles = (n + tile_keys - 1) / tile_keys;
     uint32_t *row = counts + (size_t)blockIdx.x * max_tiles;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -76,19 +100,16 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ counts
     if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
-__global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ d_n,
-    uint32_t max_n, uint32_t shift, uint32_t mask, const uint32_t *__restrict__ counts,
-    const uint32_t *__restrict__ totals, uint32_t max_tiles) {
-    const uint32_t n = min(*d_n, max_n);
+template <uint32_t ITEMS>
+__device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys_in,
+                                               const uint32_t *__restrict__ vals_in,
+                                               uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                               uint32_t n, uint32_t shift, uint32_t mask,
+                                               const uint32_t *__restrict__ counts,
+                                               const uint32_t *__restrict__ totals, uint32_t max_tiles,
+                                               uint32_t (*wave_hist)[kRadix], uint32_t *digit_base,
+                                               uint32_t *wave_tot) {
     const uint32_t tile = blockIdx.x;
-    if (tile * kSortTile >= n) return;
-
-    __shared__ uint32_t wave_hist[kSortWaves][kRadix];
-    __shared__ uint32_t digit_base[kRadix];
-    __shared__ uint32_t wave_tot[kSortWaves];
-
     const uint32_t wid = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
     for (uint32_t i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&wave_hist[0][0])[i] = 0;
@@ -105,11 +126,11 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
         digit_base[d] = off + counts[(size_t)d * max_tiles + tile];
     }
 
-    // Each wave owns a contiguous 1024-key chunk; round i covers keys chunk + i*64 + lane.
-    const uint32_t chunk = tile * kSortTile + wid * (kWave * kSortItems);
-    uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
+    // Each wave owns a contiguous chunk of 64*ITEMS keys; round i covers keys chunk + i*64 + lane.
+    const uint32_t chunk = tile * (kSortThreads * ITEMS) + wid * (kWave * ITEMS);
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
 #pragma unroll
-    for (uint32_t i = 0; i < kSortItems; i++) {
+    for (uint32_t i = 0; i < ITEMS; i++) {
         const uint32_t idx = chunk + i * kWave + lane;
         key[i] = idx < n ? keys_in[idx] : 0u;
         val[i] = idx < n ? vals_in[idx] : 0u;
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
 
     const uint64_t lt = lanemask_lt();
 #pragma unroll
-    for (uint32_t i = 0; i < kSortItems; i++) {
+    for (uint32_t i = 0; i < ITEMS; i++) {
         const uint32_t idx = chunk + i * kWave + lane;
         const bool valid = idx < n;
         const uint32_t digit = (key[i] >> shift) & mask;
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
     }
     __syncthreads();
 #pragma unroll
-    for (uint32_t i = 0; i < kSortItems; i++) {
+    for (uint32_t i = 0; i < ITEMS; i++) {
         const uint32_t idx = chunk + i * kWave + lane;
         if (idx < n) {
             const uint32_t digit = (key[i] >> shift) & mask;
@@ -163,6 +184,31 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
             vals_out[pos] = val[i];
         }
     }
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ d_n,
+    uint32_t max_n, uint32_t shift, uint32_t mask, const uint32_t *__restrict__ counts,
+    const uint32_t *__restrict__ totals, uint32_t max_tiles) {
+    const uint32_t n = min(*d_n, max_n);
+    const uint32_t items = sort_items(n);
+    if ((uint64_t)blockIdx.x * kSortThreads * items >= n) return;
+
+    __shared__ uint32_t wave_hist[kSortWaves][kRadix];
+    __shared__ uint32_t digit_base[kRadix];
+    __shared__ uint32_t wave_tot[kSortWaves];
+#define BRUSH_DOWN(K)                                                                                        \
+    downsweep_body<K>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, counts, totals, max_tiles, wave_hist, \
+                      digit_base, wave_tot)
+    switch (items) {  // block-uniform
+        case 1: BRUSH_DOWN(1); break;
+        case 2: BRUSH_DOWN(2); break;
+        case 4: BRUSH_DOWN(4); break;
+        case 8: BRUSH_DOWN(8); break;
+        default: BRUSH_DOWN(16); break;
+    }
+#undef BRUSH_DOWN
 }
 
 __global__ void k_sort_copy(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
@@ -184,7 +230,7 @@ struct SortWs {
 SortWs carve_sort(void *ws, uint32_t max_n) {
     SortWs w;
     Carver c(ws);
-    w.max_tiles = ceil_div(max_n ? max_n : 1, kSortTile);
+    w.max_tiles = sort_max_tiles(max_n ? max_n : 1);
     w.tmp_keys = c.take<uint32_t>(max_n ? max_n : 1);
     w.tmp_vals = c.take<uint32_t>(max_n ? max_n : 1);
     w.counts = c.take<uint32_t>((size_t)kRadix * w.max_tiles);
@@ -205,7 +251,7 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
     const uint32_t total_bits = 4u * ((bits + 3u) / 4u);  // brush-sort/src/lib.rs:58
     const uint32_t passes = (total_bits + 7u) / 8u;
     if (passes == 0) {
-        hipLaunchKernelGGL(k_sort_copy, dim3(min(w.max_tiles * 4u, 2048u)), dim3(256), 0, s, keys_in, vals_in,
+        hipLaunchKernelGGL(k_sort_copy, dim3(min(w.max_tiles, 2048u)), dim3(256), 0, s, keys_in, vals_in,
                            keys_out, vals_out, d_n, max_n);
         return hipGetLastError();
     }

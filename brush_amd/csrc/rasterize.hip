@@ -47,24 +47,33 @@ __device__ __forceinline__ void stage_splat(SplatLds &lds, uint32_t slot, const 
     lds.o[slot] = p[8];
 }
 
-// Every XCD (blocks b, b+8, b+16, ... share one) gets a contiguous band of tile ids.
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t num_tiles) {
-    const uint32_t per = (num_tiles + 7u) / 8u;
-    return (bid & 7u) * per + (bid >> 3);
+constexpr uint32_t kTilesPerBlock = 4;  // 4 independent wave64s per 256-thread workgroup
+constexpr uint32_t kRasterThreads = kTilesPerBlock * kWave;
+
+// Every XCD (blocks b, b+8, b+16, ... share one) gets a contiguous band of tile ids; wave `wv` of
+// block `bid` takes one tile.  The grid has a multiple of 8 blocks.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t nblocks, uint32_t wv) {
+    const uint32_t per = nblocks >> 3;
+    return ((bid & 7u) * per + (bid >> 3)) * kTilesPerBlock + wv;
 }
+// The waves of a workgroup never exchange data: LDS hand-offs are wave-local, the LDS queue of a
+// wave is in order, so a compiler-level barrier is all that is needed (no s_barrier).
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
 template <bool RASTER_U32>
-__global__ __launch_bounds__(kWave) void k_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles,
+__global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles,
                                                      const uint32_t *__restrict__ gid_from_isect,
                                                      const uint32_t *__restrict__ tile_bins,
                                                      const float *__restrict__ projected,
                                                      void *__restrict__ out_img,
                                                      uint32_t *__restrict__ final_index) {
-    __shared__ SplatLds lds;
-    const uint32_t tile_id = xcd_tile(blockIdx.x, num_tiles);
+    __shared__ SplatLds lds_all[kTilesPerBlock];
+    const uint32_t wv = threadIdx.x / kWave;
+    SplatLds &lds = lds_all[wv];
+    const uint32_t tile_id = xcd_tile(blockIdx.x, gridDim.x, wv);
     if (tile_id >= num_tiles) return;
     const uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t px0 = tile_x * kTileWidth + (lane & 3u) * kPix;
     const uint32_t py = tile_y * kTileWidth + (lane >> 2);
     const float pcy = (float)py + 0.5f;  // rasterize.wgsl:32
@@ -85,12 +94,12 @@ __global__ __launch_bounds__(kWave) void k_rasterize(uint32_t w, uint32_t h, uin
     for (uint32_t batch_start = r0; batch_start < r1; batch_start += kBatch) {
         if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
         const uint32_t remaining = min(kBatch, r1 - batch_start);
-        __builtin_amdgcn_wave_barrier();
+        wave_sync();
         if (lane < remaining) {
             const uint32_t cg_id = gid_from_isect[batch_start + lane];
             stage_splat(lds, lane, projected + (size_t)cg_id * BRUSH_PROJECTED_FLOATS);
         }
-        __syncthreads();  // single wave: orders the LDS writes before the broadcast reads
+        wave_sync();
         for (uint32_t t = 0; t < remaining; t++) {
             const float4 a = lds.a[t];
             const float4 b = lds.b[t];
@@ -101,23 +110,22 @@ __global__ __launch_bounds__(kWave) void k_rasterize(uint32_t w, uint32_t h, uin
             const float dx0 = a.x - pcx0;
 #pragma unroll
             for (uint32_t j = 0; j < kPix; j++) {
+                // Branch-free form of rasterize.wgsl:80-99 (selects, no exec-mask juggling).
                 const float dx = dx0 - (float)j;
                 const float sigma = 0.5f * (a.z * dx * dx + cdy2) + bdy * dx;
                 const float vis = __expf(-sigma);
                 const float alpha = fminf(0.999f, opac * vis);
-                if (!done[j] && sigma >= 0.0f && alpha >= 1.0f / 255.0f) {
-                    const float next_T = T[j] * (1.0f - alpha);
-                    if (next_T <= 1e-4f) {
-                        done[j] = true;  // rasterize.wgsl:88-91: stop without adding this entry
-                    } else {
-                        const float fac = alpha * T[j];
-                        cr[j] += b.y * fac;
-                        cg[j] += b.z * fac;
-                        cb[j] += b.w * fac;
-                        T[j] = next_T;
-                        fin[j] = batch_start + t;
-                    }
-                }
+                const bool hit = !done[j] && sigma >= 0.0f && alpha >= 1.0f / 255.0f;
+                const float next_T = T[j] * (1.0f - alpha);
+                const bool stop = hit && next_T <= 1e-4f;  // :88-91: stop without adding this entry
+                const bool add = hit && !stop;
+                const float fac = alpha * T[j];
+                cr[j] = add ? __builtin_fmaf(b.y, fac, cr[j]) : cr[j];
+                cg[j] = add ? __builtin_fmaf(b.z, fac, cg[j]) : cg[j];
+                cb[j] = add ? __builtin_fmaf(b.w, fac, cb[j]) : cb[j];
+                T[j] = add ? next_T : T[j];
+                fin[j] = add ? batch_start + t : fin[j];
+                done[j] = done[j] || stop;
             }
             if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
         }
@@ -167,22 +175,26 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(kWave) void k_rasterize_backward(
+__global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
     uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles, const uint32_t *__restrict__ gid_from_isect,
     const uint32_t *__restrict__ tile_bins, const float *__restrict__ projected,
     const uint32_t *__restrict__ final_index, const float *__restrict__ out_img,
     const float *__restrict__ v_out, float *__restrict__ v_compact) {
-    __shared__ SplatLds lds;
-    __shared__ uint32_t lds_gid[kBatch];
-    __shared__ float acc[kBatch][12];  // 9 used; 48-byte rows keep the b128 stores aligned
+    __shared__ SplatLds lds_all[kTilesPerBlock];
+    __shared__ uint32_t lds_gid_all[kTilesPerBlock][kBatch];
+    __shared__ float acc_all[kTilesPerBlock][kBatch][12];  // 9 used; 48-byte rows keep b128 stores aligned
 
-    const uint32_t tile_id = xcd_tile(blockIdx.x, num_tiles);
+    const uint32_t wv = threadIdx.x / kWave;
+    SplatLds &lds = lds_all[wv];
+    uint32_t *lds_gid = lds_gid_all[wv];
+    float(*acc)[12] = acc_all[wv];
+    const uint32_t tile_id = xcd_tile(blockIdx.x, gridDim.x, wv);
     if (tile_id >= num_tiles) return;
     const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
     if (r1 <= r0) return;
 
     const uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t px0 = tile_x * kTileWidth + (lane & 3u) * kPix;
     const uint32_t py = tile_y * kTileWidth + (lane >> 2);
     const float pcy = (float)py + 0.5f;
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(kWave) void k_rasterize_backward(
     // Batches walk the list back to front (rasterize_backwards.wgsl:194-208).
     for (uint32_t batch_end = r1; batch_end > r0;) {
         const uint32_t remaining = min(kBatch, batch_end - r0);
-        __syncthreads();  // previous batch fully flushed
+        wave_sync();  // previous batch fully flushed
         if (lane < remaining) {
             const uint32_t cg_id = gid_from_isect[batch_end - 1u - lane];
             lds_gid[lane] = cg_id;
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(kWave) void k_rasterize_backward(
             float4 *row = reinterpret_cast<float4 *>(&acc[lane][0]);
             row[0] = row[1] = row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
+        wave_sync();
 
         for (uint32_t t = 0; t < remaining; t++) {
             const uint32_t isect_id = batch_end - 1u - t;
@@ -236,42 +248,52 @@ __global__ __launch_bounds__(kWave) void k_rasterize_backward(
             float g[kGradComps];
 #pragma unroll
             for (uint32_t k = 0; k < kGradComps; k++) g[k] = 0.0f;
-            bool any = false;
+            // Pass 1 (cheap, branch-free): alpha and the contribution mask of the 4 pixels.
+            float vis[kPix], alpha[kPix];
+            bool m[kPix];
 #pragma unroll
             for (uint32_t j = 0; j < kPix; j++) {
                 const float dx = dx0 - (float)j;
-                const float adx = a.z * dx;
-                const float sigma = 0.5f * (adx * dx + cdy2) + bdy * dx;
-                const float vis = __expf(-sigma);
-                const float alpha = fminf(0.99f, opac * vis);  // 0.99 here (rasterize_backwards.wgsl:239)
-                if (inside[j] && isect_id <= fin[j] && sigma >= 0.0f && alpha >= 1.0f / 255.0f) {
-                    any = true;
-                    // v_rcp_f32 (1 ulp) + one Newton step: the T *= ra chain runs over the whole
-                    // list, so the reciprocal is refined to ~0.5 ulp for 2 extra FMAs.
-                    const float om = 1.0f - alpha;
-                    float ra = __builtin_amdgcn_rcpf(om);
-                    ra = __builtin_fmaf(__builtin_fmaf(-om, ra, 1.0f), ra, ra);
-                    T[j] *= ra;
-                    const float fac = alpha * T[j];
-                    float v_alpha = (b.y * T[j] - bufr[j] * ra) * vo[j].x + (b.z * T[j] - bufg[j] * ra) * vo[j].y +
-                                    (b.w * T[j] - bufb[j] * ra) * vo[j].z;
-                    v_alpha += T_final[j] * ra * vo[j].w;
-                    bufr[j] += b.y * fac;
-                    bufg[j] += b.z * fac;
-                    bufb[j] += b.w * fac;
-                    const float v_sigma = -opac * vis * v_alpha;
-                    g[0] += v_sigma * (adx + bdy);
-                    g[1] += v_sigma * (a.w * dx + cdy);
-                    g[2] += 0.5f * v_sigma * dx * dx;
-                    g[3] += v_sigma * dx * dy;
-                    g[4] += 0.5f * v_sigma * dy * dy;
-                    g[5] += fac * vo[j].x;
-                    g[6] += fac * vo[j].y;
-                    g[7] += fac * vo[j].z;
-                    g[8] += vis * v_alpha;
-                }
+                const float sigma = 0.5f * (a.z * dx * dx + cdy2) + bdy * dx;
+                vis[j] = __expf(-sigma);
+                alpha[j] = fminf(0.99f, opac * vis[j]);  // 0.99 here (rasterize_backwards.wgsl:239)
+                m[j] = inside[j] && isect_id <= fin[j] && sigma >= 0.0f && alpha[j] >= 1.0f / 255.0f;
             }
-            if (__ballot(any) != 0ull) {  // wave-uniform
+            const bool any = __ballot(m[0] || m[1] || m[2] || m[3]) != 0ull;
+            // Pass 2: rasterize_backwards.wgsl:244-271 with selects; a pixel column no lane of the
+            // wave contributes to is skipped by a wave-uniform (scalar) branch.
+#pragma unroll
+            for (uint32_t j = 0; j < kPix; j++) {
+                if (__ballot(m[j]) == 0ull) continue;
+                const float dx = dx0 - (float)j;
+                const float adx = a.z * dx;
+                // v_rcp_f32 (1 ulp) + one Newton step; 1 - alpha >= 0.01 so this is always finite.
+                const float om = 1.0f - alpha[j];
+                float ra = __builtin_amdgcn_rcpf(om);
+                ra = __builtin_fmaf(__builtin_fmaf(-om, ra, 1.0f), ra, ra);
+                const float Tn = T[j] * ra;
+                const float fac = alpha[j] * Tn;
+                float v_alpha = (b.y * Tn - bufr[j] * ra) * vo[j].x + (b.z * Tn - bufg[j] * ra) * vo[j].y +
+                                (b.w * Tn - bufb[j] * ra) * vo[j].z;
+                v_alpha += T_final[j] * ra * vo[j].w;
+                T[j] = m[j] ? Tn : T[j];
+                bufr[j] = m[j] ? __builtin_fmaf(b.y, fac, bufr[j]) : bufr[j];
+                bufg[j] = m[j] ? __builtin_fmaf(b.z, fac, bufg[j]) : bufg[j];
+                bufb[j] = m[j] ? __builtin_fmaf(b.w, fac, bufb[j]) : bufb[j];
+                const float vis_m = m[j] ? vis[j] * v_alpha : 0.0f;  // v_opac term
+                const float v_sigma = -opac * vis_m;                  // 0 when masked
+                const float fac_m = m[j] ? fac : 0.0f;
+                g[0] = __builtin_fmaf(v_sigma, adx + bdy, g[0]);
+                g[1] = __builtin_fmaf(v_sigma, a.w * dx + cdy, g[1]);
+                g[2] = __builtin_fmaf(0.5f * v_sigma, dx * dx, g[2]);
+                g[3] = __builtin_fmaf(v_sigma, dx * dy, g[3]);
+                g[4] = __builtin_fmaf(0.5f * v_sigma, dy * dy, g[4]);
+                g[5] = __builtin_fmaf(fac_m, vo[j].x, g[5]);
+                g[6] = __builtin_fmaf(fac_m, vo[j].y, g[6]);
+                g[7] = __builtin_fmaf(fac_m, vo[j].z, g[7]);
+                g[8] += vis_m;
+            }
+            if (any) {  // wave-uniform
 #pragma unroll
                 for (uint32_t k = 0; k < kGradComps; k++) g[k] = wave_sum_lane63(g[k]);
                 if (lane == 63) {
@@ -282,7 +304,7 @@ __global__ __launch_bounds__(kWave) void k_rasterize_backward(
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         // Flush: one hardware float atomic per (tile, splat, component); consecutive lanes take
         // consecutive components of one splat (MI355X_MICROARCH.md, global float atomics).
         for (uint32_t f = lane; f < remaining * kGradComps; f += kWave) {
@@ -302,7 +324,7 @@ hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                             hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
-    const dim3 grid(ceil_div(tiles, 8u) * 8u), block(kWave);
+    const dim3 grid(ceil_div(ceil_div(tiles, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
     if (raster_u32) {
         hipLaunchKernelGGL(k_rasterize<true>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins,
                            projected, out_img, final_index);
@@ -320,7 +342,7 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
                                      hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
-    const dim3 grid(ceil_div(tiles, 8u) * 8u), block(kWave);
+    const dim3 grid(ceil_div(ceil_div(tiles, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
     hipLaunchKernelGGL(k_rasterize_backward, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins,
                        projected, final_index, out_img, v_out, v_compact);
     return hipGetLastError();

@@ -175,12 +175,10 @@ extern "C" int brush_render_forward(const BrushUniforms *h_uniforms, const float
     const uint32_t num_tiles = tbx * tby;
 
     mark_fwd(s, 0);
-    // uniforms buffer, counters, tile_bins = 0
-    BRUSH_HIP_CHECK(launch_init(u, aux, num_tiles, s));
-    // ProjectSplats + order-preserving compaction (render.rs:123-142)
-    BRUSH_HIP_CHECK(launch_project_cull(vp, means, log_scales, quats, ws.key_all, aux.compact_from_global_gid,
-                                        ws.block_counts, aux.num_visible, aux.uniforms_buffer, ws.pre_keys,
-                                        ws.pre_gids, s));
+    // uniforms buffer, counters, tile_bins = 0; ProjectSplats + order-preserving compaction
+    // (render.rs:102-142)
+    BRUSH_HIP_CHECK(launch_project_cull(vp, u, aux, num_tiles, means, log_scales, quats, ws.key_all,
+                                        ws.block_counts, ws.pre_keys, ws.pre_gids, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_CULL);
     // DepthSort: keys = f32 depth bits, all 32 bits (render.rs:151-156)
     BRUSH_HIP_CHECK(sort_launch(ws.pre_keys, ws.pre_gids, ws.sorted_keys, aux.global_from_compact_gid,
