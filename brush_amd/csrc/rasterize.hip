@@ -165,6 +165,26 @@ __device__ __forceinline__ float dpp_add(float v) {
     const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
     return v + __int_as_float(moved);
 }
+// Row-of-16 inclusive scan: the row total is valid in lane 15 of each row.
+__device__ __forceinline__ float row_sum_lane15(float v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    return v;
+}
+// Transposing pair reductions with the gfx950 lane-swap instructions: one swap + one add fold two
+// registers into one in which half of the lanes carry the pair sums of `a`, the other half of `b`.
+//   swap32: lanes 0-31 <- a[l] + a[l+32],   lanes 32-63 <- b[l-32] + b[l]
+//   swap16: even rows  <- a[row] + a[row+1], odd rows   <- b[row-1] + b[row]
+__device__ __forceinline__ float fold_swap32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold_swap16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float wave_sum_lane63(float v) {
     v = dpp_add<0x111, 0xf>(v);  // row_shr:1
     v = dpp_add<0x112, 0xf>(v);  // row_shr:2
@@ -201,23 +221,27 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
     const float pcx0 = (float)px0 + 0.5f;
 
     bool inside[kPix];
-    float T[kPix], T_final[kPix], bufr[kPix], bufg[kPix], bufb[kPix];
+    // Per-pixel state.  The reference's running colour `buffer` (rasterize_backwards.wgsl:253-257)
+    // only ever appears dotted with the pixel's constant v_out.rgb, so the scalar
+    // D = sum_j fac_j * (c_j . v_rgb) carries the same information; K = T_final * v_out.a.
+    float T[kPix], K[kPix], D[kPix];
     float4 vo[kPix];
     uint32_t fin[kPix];
 #pragma unroll
     for (uint32_t j = 0; j < kPix; j++) {
         inside[j] = px0 + j < w && py < h;
-        T_final[j] = 1.0f;
+        float T_final = 1.0f;
         fin[j] = 0;
         vo[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (inside[j]) {
             const size_t pix = (size_t)(px0 + j) + (size_t)py * w;
-            T_final[j] = 1.0f - out_img[pix * 4 + 3];  // rasterize_backwards.wgsl:163
+            T_final = 1.0f - out_img[pix * 4 + 3];  // rasterize_backwards.wgsl:163
             fin[j] = final_index[pix];
             vo[j] = reinterpret_cast<const float4 *>(v_out)[pix];
         }
-        T[j] = T_final[j];
-        bufr[j] = bufg[j] = bufb[j] = 0.0f;
+        T[j] = T_final;
+        K[j] = T_final * vo[j].w;
+        D[j] = 0.0f;
     }
 
     // Batches walk the list back to front (rasterize_backwards.wgsl:194-208).
@@ -273,13 +297,12 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
                 ra = __builtin_fmaf(__builtin_fmaf(-om, ra, 1.0f), ra, ra);
                 const float Tn = T[j] * ra;
                 const float fac = alpha[j] * Tn;
-                float v_alpha = (b.y * Tn - bufr[j] * ra) * vo[j].x + (b.z * Tn - bufg[j] * ra) * vo[j].y +
-                                (b.w * Tn - bufb[j] * ra) * vo[j].z;
-                v_alpha += T_final[j] * ra * vo[j].w;
+                // v_alpha = (c*T - buffer*ra) . v_rgb + T_final*ra*v_a  (rasterize_backwards.wgsl:253-254)
+                //         = T*(c . v_rgb) + ra*(K - D)
+                const float cv = b.y * vo[j].x + b.z * vo[j].y + b.w * vo[j].z;
+                const float v_alpha = __builtin_fmaf(Tn, cv, ra * (K[j] - D[j]));
                 T[j] = m[j] ? Tn : T[j];
-                bufr[j] = m[j] ? __builtin_fmaf(b.y, fac, bufr[j]) : bufr[j];
-                bufg[j] = m[j] ? __builtin_fmaf(b.z, fac, bufg[j]) : bufg[j];
-                bufb[j] = m[j] ? __builtin_fmaf(b.w, fac, bufb[j]) : bufb[j];
+                D[j] = m[j] ? __builtin_fmaf(fac, cv, D[j]) : D[j];
                 const float vis_m = m[j] ? vis[j] * v_alpha : 0.0f;  // v_opac term
                 const float v_sigma = -opac * vis_m;                  // 0 when masked
                 const float fac_m = m[j] ? fac : 0.0f;
@@ -293,14 +316,21 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
                 g[7] = __builtin_fmaf(fac_m, vo[j].z, g[7]);
                 g[8] += vis_m;
             }
-            if (any) {  // wave-uniform
-#pragma unroll
-                for (uint32_t k = 0; k < kGradComps; k++) g[k] = wave_sum_lane63(g[k]);
-                if (lane == 63) {
-                    float4 *row = reinterpret_cast<float4 *>(&acc[t][0]);
-                    row[0] = make_float4(g[0], g[1], g[2], g[3]);
-                    row[1] = make_float4(g[4], g[5], g[6], g[7]);
-                    acc[t][8] = g[8];
+            if (any) {  // wave-uniform: all 64 lanes take part in the reduction
+                // 8 components: two transposing folds (lane-swap + add), then a row-of-16 scan of
+                // the two survivors; component 8 takes the plain 6-step DPP sum.  26 VALU ops.
+                const float u0 = fold_swap32(g[0], g[1]), u1 = fold_swap32(g[2], g[3]);
+                const float u2 = fold_swap32(g[4], g[5]), u3 = fold_swap32(g[6], g[7]);
+                const float w0 = row_sum_lane15(fold_swap16(u0, u1));
+                const float w1 = row_sum_lane15(fold_swap16(u2, u3));
+                const float s8 = wave_sum_lane63(g[8]);
+                if ((lane & 15u) == 15u) {
+                    // row r: w0 holds component ((r&1)<<1 | r>>1), w1 the same + 4
+                    const uint32_t r = lane >> 4;
+                    const uint32_t i0 = ((r & 1u) << 1) | (r >> 1);
+                    acc[t][i0] = w0;
+                    acc[t][4 + i0] = w1;
+                    if (lane == 63) acc[t][8] = s8;
                 }
             }
         }
