@@ -100,6 +100,7 @@ def main():
     n_gpus = world
 
     import brush_amd
+    from brush_amd import dist as BD
     from brush_amd import render as R
     from brush_amd.profiler import StageProfiler
 
@@ -112,8 +113,7 @@ def main():
     # upstream gradient of mean(img) (render_bench.rs:180)
     v_out = torch.full((h, w, 4), 1.0 / (4 * w * h), dtype=torch.float32, device=dev)
     layout, total = R.grad_block_layout(n, C)
-    block = torch.empty(total, dtype=torch.float32, device=dev)
-    param_floats = layout["v_sh"][0] + layout["v_sh"][1]  # [means|scales|quats|opac|sh] contiguous prefix
+    block = torch.zeros(total, dtype=torch.float32, device=dev)
 
     def fwd_bwd():
         out, aux, u = R._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"],
@@ -143,7 +143,7 @@ def main():
         else:
             aux = fwd_bwd()
         if world > 1:
-            dist.all_reduce(block[:param_floats])  # dense gradient block, sum over views
+            BD.allreduce_param_grads(block, n, C)  # one RCCL all-reduce of the dense gradient prefix
         return aux
 
     def barrier():

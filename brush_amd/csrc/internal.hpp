@@ -7,19 +7,27 @@ namespace brush {
 struct ViewParams;
 
 // project.hip
+// Device work queue of (splat, tile-chunk) items for the balanced tile walks.
+struct WalkWs {
+    uint32_t *counter;      // [1]
+    uint32_t *items;        // [capacity * 2]
+    uint32_t *chunk_count;  // [capacity]
+    uint32_t *slot_of;      // [N]
+    uint32_t capacity;
+};
 size_t cull_block_count(uint32_t n);
 hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, const BrushAux &aux,
                                uint32_t num_tiles, const float *means, const float *log_scales,
                                const float *quats, uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
-                               uint32_t *gids, hipStream_t s);
+                               uint32_t *gids, uint32_t *walk_counter, hipStream_t s);
 hipError_t launch_project_visible(const ViewParams &vp, const float *means, const float *log_scales,
                                   const float *quats, const float *sh, const float *raw_opac,
                                   const uint32_t *num_visible, uint32_t *global_from_compact,
                                   uint32_t *compact_from_global, float *projected, uint32_t *tiles_hit,
-                                  hipStream_t s);
+                                  const WalkWs &walk, hipStream_t s);
 hipError_t launch_map_intersects(const ViewParams &vp, const float *projected, const uint32_t *cum_tiles_hit,
                                  const uint32_t *num_visible, uint32_t cap, uint32_t *tile_ids, uint32_t *gids,
-                                 hipStream_t s);
+                                 const WalkWs &walk, hipStream_t s);
 hipError_t launch_tile_bin_edges(const uint32_t *sorted_tile_ids, const uint32_t *num_intersections,
                                  uint32_t cap, uint32_t *tile_bins, hipStream_t s);
 

@@ -29,154 +29,66 @@ namespace brush {
 namespace {
 
 constexpr uint32_t kThreads = 256;
-// Bboxes above this many tiles are walked by the whole workgroup (256 tiles per step) instead of
-// by their owning lane: the nearest splats cover thousands of tiles.
-constexpr uint32_t kCoopArea = 8;
+// Tile walks.  A splat's bbox holds 1 .. tiles_x*tiles_y candidate tiles and the exact
+// can_be_visible test costs ~300 VALU instructions, so the walk is split by size:
+//   * bboxes of <= kSmallArea tiles are walked by their own lane, inline;
+//   * larger ones are cut into chunks of kChunkTiles tiles and queued as (splat, chunk) work items
+//     (one atomicAdd reserves a splat's consecutive slots).  A second launch consumes the queue
+//     one wave64 per item, 64 tiles per step, so a whole-screen splat is spread over dozens of
+//     waves and no lane ever walks more than kSmallArea tiles.
+// If the queue is full the lane falls back to walking its bbox inline (slow, still correct).
+constexpr uint32_t kSmallArea = 8;
+constexpr uint32_t kChunkTiles = 256;
 
-// Compact ids are in depth order, so the nearest (largest-footprint) splats are neighbours.
-// To keep them out of one wave, lane t of block b takes the 4 consecutive ids of group
-// (t/4)*gridDim + b: neighbours in depth order land in different workgroups, while each
-// group's 4 x 36 B records still form one contiguous 144-byte run.
-__device__ __forceinline__ uint32_t interleaved_id(uint32_t round, uint32_t tid, uint32_t bid, uint32_t nblocks) {
-    return round * (nblocks * kThreads) + tid * nblocks + bid;
-}
-
-// Descriptor of a splat whose bbox is walked by the whole workgroup.
-struct BigSplat {
-    float q[3];
-    float xy[2];
-    uint32_t any;
-    uint32_t b0, b1, bw, area;
-    uint32_t c, isect;
+struct WalkQueue {
+    uint32_t *counter;      // [1] items reserved so far (zeroed by the cull kernel)
+    uint2 *items;           // [capacity] (compact gid, chunk index)
+    uint32_t *chunk_count;  // [capacity] tiles hit inside the chunk (written by the count pass)
+    uint32_t *slot_of;      // [N] first item slot of a queued splat, kInvalid if walked inline
+    uint32_t capacity;
 };
 
-struct WalkShared {
-    BigSplat big[kThreads];
-    uint32_t count[kThreads];
-    uint32_t wave_cnt[kThreads / kWave];
-    uint32_t nbig;
-};
-
-__device__ __forceinline__ bool big_hit(const BigSplat &d, uint32_t i, uint32_t &tx, uint32_t &ty) {
-    TileTest st;
-    st.q[0] = d.q[0];
-    st.q[1] = d.q[1];
-    st.q[2] = d.q[2];
-    st.any = d.any != 0;
-    tx = d.b0 + i % d.bw;
-    ty = d.b1 + i / d.bw;
-    return can_be_visible(st, tx, ty, d.xy);
-}
-
-// Queue this lane's splat for the workgroup walk; returns its slot.  Called between two
-// __syncthreads() that bracket the zeroing of sh.nbig and the reading of the list.
-__device__ __forceinline__ uint32_t push_big(WalkShared &sh, const uint32_t bb[4], const TileTest &tt,
-                                             const float xy[2], uint32_t area, uint32_t c, uint32_t isect) {
-    const uint32_t slot = atomicAdd(&sh.nbig, 1u);
-    BigSplat d;
-    d.q[0] = tt.q[0];
-    d.q[1] = tt.q[1];
-    d.q[2] = tt.q[2];
-    d.xy[0] = xy[0];
-    d.xy[1] = xy[1];
-    d.any = tt.any ? 1u : 0u;
-    d.b0 = bb[0];
-    d.b1 = bb[1];
-    d.bw = bb[2] - bb[0];
-    d.area = area;
-    d.c = c;
-    d.isect = isect;
-    sh.big[slot] = d;
-    sh.count[slot] = 0;
-    return slot;
-}
-
-// Number of bbox tiles that pass can_be_visible for this lane's splat.  Must be called by every
-// thread of the workgroup (inactive lanes pass active = false).  Small bboxes are walked by their
-// lane; bboxes above kCoopArea tiles are walked by all 256 threads, 256 tiles per step.
-__device__ __forceinline__ uint32_t count_tiles(WalkShared &sh, bool active, const uint32_t bb[4],
-                                                const TileTest &tt, const float xy[2]) {
-    const uint32_t bw = bb[2] - bb[0], bh = bb[3] - bb[1];
-    const uint32_t area = active ? bw * bh : 0u;
-    const bool big = area > kCoopArea;
-    if (threadIdx.x == 0) sh.nbig = 0;
-    __syncthreads();
-    uint32_t cnt = 0, slot = 0;
-    if (active && !big) {
-        for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
-            for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
-                if (can_be_visible(tt, tx, ty, xy)) cnt++;
-    }
-    if (big) slot = push_big(sh, bb, tt, xy, area, 0u, 0u);
-    __syncthreads();
-    const uint32_t nbig = sh.nbig;
-    for (uint32_t b = 0; b < nbig; b++) {
-        const BigSplat d = sh.big[b];
-        uint32_t local = 0;
-        for (uint32_t i0 = 0; i0 < d.area; i0 += kThreads) {
-            const uint32_t i = i0 + threadIdx.x;
-            uint32_t tx, ty;
-            const bool hit = i < d.area && big_hit(d, i, tx, ty);
-            local += __popcll(__ballot(hit));
-        }
-        if (lane_id() == 0 && local) atomicAdd(&sh.count[b], local);
-    }
-    __syncthreads();
-    if (big) cnt = sh.count[slot];
+__device__ __forceinline__ uint32_t walk_inline_count(const uint32_t bb[4], const TileTest &tt, const float xy[2]) {
+    uint32_t cnt = 0;
+    for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
+        for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
+            if (can_be_visible(tt, tx, ty, xy)) cnt++;
     return cnt;
 }
 
-// Emits (tile id, compact gid) for every passing bbox tile in row-major order starting at
-// `isect`.  Same calling convention as count_tiles.
-__device__ __forceinline__ void emit_tiles(WalkShared &sh, bool active, uint32_t c, uint32_t isect,
-                                           const uint32_t bb[4], const TileTest &tt, const float xy[2],
-                                           uint32_t tbx, uint32_t cap, uint32_t *__restrict__ tile_ids,
-                                           uint32_t *__restrict__ gids) {
-    const uint32_t bw = bb[2] - bb[0], bh = bb[3] - bb[1];
-    const uint32_t area = active ? bw * bh : 0u;
-    const bool big = area > kCoopArea;
-    if (threadIdx.x == 0) sh.nbig = 0;
-    __syncthreads();
-    if (active && !big) {
-        for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
-            for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
-                if (can_be_visible(tt, tx, ty, xy) && isect < cap) {
-                    tile_ids[isect] = tx + ty * tbx;
-                    gids[isect] = c;
-                    isect++;
-                }
-    }
-    if (big) push_big(sh, bb, tt, xy, area, c, isect);
-    __syncthreads();
-    const uint32_t nbig = sh.nbig;
-    const uint32_t wid = threadIdx.x / kWave;
-    const uint64_t lt = lanemask_lt();
-    for (uint32_t b = 0; b < nbig; b++) {
-        const BigSplat d = sh.big[b];
-        uint32_t run = d.isect;
-        for (uint32_t i0 = 0; i0 < d.area; i0 += kThreads) {
-            const uint32_t i = i0 + threadIdx.x;
-            uint32_t tx = 0, ty = 0;
-            const bool hit = i < d.area && big_hit(d, i, tx, ty);
-            const uint64_t bal = __ballot(hit);
-            if (lane_id() == 0) sh.wave_cnt[wid] = __popcll(bal);
-            __syncthreads();
-            uint32_t pos = run + __popcll(bal & lt);
-            uint32_t total = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < kThreads / kWave; w++) {
-                const uint32_t wc = sh.wave_cnt[w];
-                if (w < wid) pos += wc;
-                total += wc;
+__device__ __forceinline__ void walk_inline_emit(const uint32_t bb[4], const TileTest &tt, const float xy[2],
+                                                 uint32_t c, uint32_t isect, uint32_t tbx, uint32_t cap,
+                                                 uint32_t *__restrict__ tile_ids, uint32_t *__restrict__ gids) {
+    for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
+        for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
+            if (can_be_visible(tt, tx, ty, xy) && isect < cap) {
+                tile_ids[isect] = tx + ty * tbx;
+                gids[isect] = c;
+                isect++;
             }
-            if (hit && pos < cap) {
-                tile_ids[pos] = tx + ty * tbx;
-                gids[pos] = d.c;
-            }
-            run += total;
-            __syncthreads();
-        }
-    }
+}
+
+// Geometry of one queued splat, rebuilt from its ProjectedSplat record.
+struct SplatWalk {
+    float xy[2];
+    TileTest tt;
+    uint32_t b0, b1, bw, area;
+};
+__device__ __forceinline__ SplatWalk load_walk(const ViewParams &vp, const float *__restrict__ projected, uint32_t c) {
+    const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
+    SplatWalk s;
+    s.xy[0] = p[0];
+    s.xy[1] = p[1];
+    const float conic[3] = {p[2], p[3], p[4]};
+    const uint32_t radius = radius_from_conic(conic);
+    uint32_t bb[4];
+    get_tile_bbox(s.xy, radius, vp.tile_bounds, bb);
+    s.tt = make_tile_test(conic, p[8]);
+    s.b0 = bb[0];
+    s.b1 = bb[1];
+    s.bw = bb[2] - bb[0];
+    s.area = s.bw * (bb[3] - bb[1]);
+    return s;
 }
 
 // ---- ProjectSplats: cull + depth key ------------------------------------------------------
@@ -193,13 +105,15 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                                            uint32_t *__restrict__ uniforms_buffer,
                                                            uint32_t *__restrict__ num_intersections,
                                                            uint32_t *__restrict__ overflow,
-                                                           uint32_t *__restrict__ tile_bins, uint32_t num_bin_words) {
+                                                           uint32_t *__restrict__ tile_bins, uint32_t num_bin_words,
+                                                           uint32_t *__restrict__ walk_counter) {
     __shared__ uint32_t wave_cnt[kThreads / kWave];
     const uint32_t g = blockIdx.x * kThreads + threadIdx.x;
     if (g < kUniformWords) uniforms_buffer[g] = reinterpret_cast<const uint32_t *>(&u)[g];
     if (g == 0) {
         *num_intersections = 0;
         *overflow = 0;
+        *walk_counter = 0;
     }
     for (uint32_t i = g; i < num_bin_words; i += gridDim.x * kThreads) tile_bins[i] = 0;
     bool visible = false;
@@ -293,19 +207,16 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
     ViewParams vp, const float *__restrict__ means, const float *__restrict__ log_scales,
     const float *__restrict__ quats, const float *__restrict__ sh_coeffs, const float *__restrict__ raw_opac,
     const uint32_t *__restrict__ num_visible, uint32_t *__restrict__ global_from_compact,
-    uint32_t *__restrict__ compact_from_global, float *__restrict__ projected, uint32_t *__restrict__ tiles_hit) {
-    __shared__ WalkShared sh;
+    uint32_t *__restrict__ compact_from_global, float *__restrict__ projected, uint32_t *__restrict__ tiles_hit,
+    WalkQueue q) {
     const uint32_t V = *num_visible;
     const uint32_t n = vp.total_splats;
     const uint32_t ncoef = (vp.sh_degree + 1) * (vp.sh_degree + 1);
-    // Block-uniform trip count: every thread of the workgroup reaches count_tiles() together.
-    // Tail of global_from_compact_gid (never written by the sort) := 0, coalesced.
+    // Tail of global_from_compact_gid (never written by the sort) := 0.
     for (uint32_t i = V + blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
         global_from_compact[i] = 0;
-    const uint32_t rounds = (V + gridDim.x * kThreads - 1) / (gridDim.x * kThreads);
-    for (uint32_t round = 0; round < rounds; round++) {
-        const uint32_t c = interleaved_id(round, threadIdx.x, blockIdx.x, gridDim.x);
-        const bool active = c < V;
+    for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < V; c += gridDim.x * kThreads) {
+        const bool active = true;
         float xy[2] = {0.f, 0.f}, conic[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
         float opac = 0.f;
         uint32_t bb[4] = {0, 0, 0, 0};
@@ -365,7 +276,19 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
             get_tile_bbox(xy, radius, vp.tile_bounds, bb);
             tt = make_tile_test(conic, opac);
         }
-        const uint32_t area = count_tiles(sh, active, bb, tt, xy);
+        // exact tile count (project_visible.wgsl:244-250): inline for small bboxes, queued otherwise
+        const uint32_t bbox_tiles = (bb[2] - bb[0]) * (bb[3] - bb[1]);
+        uint32_t area = 0, slot = kInvalid;
+        if (bbox_tiles > kSmallArea) {
+            const uint32_t nchunks = (bbox_tiles + kChunkTiles - 1) / kChunkTiles;
+            const uint32_t first = atomicAdd(q.counter, nchunks);
+            if (first + nchunks <= q.capacity) {
+                slot = first;
+                for (uint32_t k = 0; k < nchunks; k++) q.items[first + k] = make_uint2(c, k);
+            }
+        }
+        if (slot == kInvalid) area = walk_inline_count(bb, tt, xy);
+        q.slot_of[c] = slot;
         if (active) {
             float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
             p[0] = xy[0];
@@ -382,37 +305,89 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
     }
 }
 
+// Second half of the tile count: one wave64 per queued (splat, chunk) item.
+__global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const float *__restrict__ projected,
+                                                         WalkQueue q, uint32_t *__restrict__ tiles_hit) {
+    const uint32_t n_items = min(*q.counter, q.capacity);
+    const uint32_t lane = lane_id();
+    const uint32_t waves = gridDim.x * (kThreads / kWave);
+    for (uint32_t it = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; it < n_items; it += waves) {
+        const uint2 item = q.items[it];
+        const SplatWalk s = load_walk(vp, projected, item.x);
+        const uint32_t lo = item.y * kChunkTiles, hi = min(s.area, lo + kChunkTiles);
+        uint32_t cnt = 0;
+        for (uint32_t i0 = lo; i0 < hi; i0 += kWave) {
+            const uint32_t i = i0 + lane;
+            const bool hit = i < hi && can_be_visible(s.tt, s.b0 + i % s.bw, s.b1 + i / s.bw, s.xy);
+            cnt += __popcll(__ballot(hit));
+        }
+        if (lane == 0) {
+            q.chunk_count[it] = cnt;
+            if (cnt) atomicAdd(&tiles_hit[item.x], cnt);
+        }
+    }
+}
+
 // ---- MapGaussiansToIntersect ---------------------------------------------------------------
-// map_gaussian_to_intersects.wgsl:10-48
+// map_gaussian_to_intersects.wgsl:10-48: splats walked inline by project_visible emit here inline;
+// queued splats are emitted by k_walk_emit.
 __global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, const float *__restrict__ projected,
                                                              const uint32_t *__restrict__ cum_tiles_hit,
                                                              const uint32_t *__restrict__ num_visible,
                                                              uint32_t cap, uint32_t *__restrict__ tile_ids,
-                                                             uint32_t *__restrict__ gids) {
-    __shared__ WalkShared sh;
+                                                             uint32_t *__restrict__ gids, WalkQueue q) {
     const uint32_t V = *num_visible;
-    const uint32_t rounds = (V + gridDim.x * kThreads - 1) / (gridDim.x * kThreads);
-    for (uint32_t round = 0; round < rounds; round++) {
-        const uint32_t c = interleaved_id(round, threadIdx.x, blockIdx.x, gridDim.x);
-        const bool active = c < V;
-        float xy[2] = {0.f, 0.f};
-        uint32_t bb[4] = {0, 0, 0, 0};
-        uint32_t isect = 0;
-        TileTest tt;
-        tt.q[0] = tt.q[1] = tt.q[2] = 0.f;
-        tt.any = false;
-        if (active) {
-            const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
-            xy[0] = p[0];
-            xy[1] = p[1];
-            const float conic[3] = {p[2], p[3], p[4]};
-            const float opac = p[8];
-            const uint32_t radius = radius_from_conic(conic);
-            get_tile_bbox(xy, radius, vp.tile_bounds, bb);
-            tt = make_tile_test(conic, opac);
-            isect = c > 0 ? cum_tiles_hit[c - 1] : 0u;
+    for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < V; c += gridDim.x * kThreads) {
+        if (q.slot_of[c] != kInvalid) continue;
+        const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
+        const float xy[2] = {p[0], p[1]};
+        const float conic[3] = {p[2], p[3], p[4]};
+        const uint32_t radius = radius_from_conic(conic);
+        uint32_t bb[4];
+        get_tile_bbox(xy, radius, vp.tile_bounds, bb);
+        const TileTest tt = make_tile_test(conic, p[8]);
+        const uint32_t isect = c > 0 ? cum_tiles_hit[c - 1] : 0u;
+        walk_inline_emit(bb, tt, xy, c, isect, vp.tile_bounds[0], cap, tile_ids, gids);
+    }
+}
+
+// One wave64 per queued item; the item's first output slot is the splat's exclusive prefix plus
+// the hit counts of the splat's earlier chunks (its items occupy consecutive queue slots).
+__global__ __launch_bounds__(kThreads) void k_walk_emit(ViewParams vp, const float *__restrict__ projected,
+                                                        const uint32_t *__restrict__ cum_tiles_hit, uint32_t cap,
+                                                        uint32_t *__restrict__ tile_ids, uint32_t *__restrict__ gids,
+                                                        WalkQueue q) {
+    const uint32_t n_items = min(*q.counter, q.capacity);
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    const uint32_t waves = gridDim.x * (kThreads / kWave);
+    for (uint32_t it = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; it < n_items; it += waves) {
+        const uint2 item = q.items[it];
+        const uint32_t c = item.x, k = item.y;
+        uint32_t before = 0;
+        for (uint32_t j = lane; j < k; j += kWave) before += q.chunk_count[it - k + j];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+        uint32_t run = (c > 0 ? cum_tiles_hit[c - 1] : 0u) + before;
+        const SplatWalk s = load_walk(vp, projected, c);
+        const uint32_t lo = k * kChunkTiles, hi = min(s.area, lo + kChunkTiles);
+        for (uint32_t i0 = lo; i0 < hi; i0 += kWave) {
+            const uint32_t i = i0 + lane;
+            uint32_t tx = 0, ty = 0;
+            bool hit = false;
+            if (i < hi) {
+                tx = s.b0 + i % s.bw;
+                ty = s.b1 + i / s.bw;
+                hit = can_be_visible(s.tt, tx, ty, s.xy);
+            }
+            const uint64_t bal = __ballot(hit);
+            const uint32_t pos = run + __popcll(bal & lt);
+            if (hit && pos < cap) {
+                tile_ids[pos] = tx + ty * vp.tile_bounds[0];
+                gids[pos] = c;
+            }
+            run += __popcll(bal);
         }
-        emit_tiles(sh, active, c, isect, bb, tt, xy, vp.tile_bounds[0], cap, tile_ids, gids);
     }
 }
 
@@ -438,9 +413,15 @@ __global__ __launch_bounds__(kThreads) void k_tile_bin_edges(const uint32_t *__r
 }
 
 uint32_t stride_grid(uint32_t work_items) { return max(1u, min(ceil_div(work_items, kThreads), 2048u)); }
-// The two tile-walk kernels hold ~100 VGPRs (4 workgroups per CU): a 1024-block grid is fully
-// resident on 256 CUs, so no workgroup waits for a slot behind a long tile walk.
-uint32_t walk_grid(uint32_t work_items) { return max(1u, min(ceil_div(work_items, kThreads), 1024u)); }
+WalkQueue make_queue(const WalkWs &w) {
+    WalkQueue q;
+    q.counter = w.counter;
+    q.items = reinterpret_cast<uint2 *>(w.items);
+    q.chunk_count = w.chunk_count;
+    q.slot_of = w.slot_of;
+    q.capacity = w.capacity;
+    return q;
+}
 
 }  // namespace
 
@@ -449,7 +430,7 @@ size_t cull_block_count(uint32_t n) { return ceil_div(n ? n : 1, kThreads); }
 hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, const BrushAux &aux,
                                uint32_t num_tiles, const float *means, const float *log_scales,
                                const float *quats, uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
-                               uint32_t *gids, hipStream_t s) {
+                               uint32_t *gids, uint32_t *walk_counter, hipStream_t s) {
     const uint32_t n = vp.total_splats;
     const uint32_t blocks = (uint32_t)cull_block_count(n);
     uint32_t *compact_from_global = aux.compact_from_global_gid;
@@ -457,7 +438,7 @@ hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, con
     uint32_t *uniforms_buffer = aux.uniforms_buffer;
     hipLaunchKernelGGL(k_project_cull, dim3(blocks), dim3(kThreads), 0, s, vp, u, means, log_scales, quats, key_all,
                        compact_from_global, block_counts, uniforms_buffer, aux.num_intersections, aux.overflow,
-                       aux.tile_bins, num_tiles * 2);
+                       aux.tile_bins, num_tiles * 2, walk_counter);
     hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, s, block_counts, blocks, num_visible,
                        uniforms_buffer);
     hipLaunchKernelGGL(k_compact, dim3(blocks), dim3(kThreads), 0, s, n, key_all, block_counts, keys, gids);
@@ -468,18 +449,23 @@ hipError_t launch_project_visible(const ViewParams &vp, const float *means, cons
                                   const float *quats, const float *sh, const float *raw_opac,
                                   const uint32_t *num_visible, uint32_t *global_from_compact,
                                   uint32_t *compact_from_global, float *projected, uint32_t *tiles_hit,
-                                  hipStream_t s) {
-    hipLaunchKernelGGL(k_project_visible, dim3(walk_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, means,
+                                  const WalkWs &walk, hipStream_t s) {
+    const WalkQueue q = make_queue(walk);
+    hipLaunchKernelGGL(k_project_visible, dim3(stride_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, means,
                        log_scales, quats, sh, raw_opac, num_visible, global_from_compact, compact_from_global,
-                       projected, tiles_hit);
+                       projected, tiles_hit, q);
+    hipLaunchKernelGGL(k_walk_count, dim3(1024), dim3(kThreads), 0, s, vp, projected, q, tiles_hit);
     return hipGetLastError();
 }
 
 hipError_t launch_map_intersects(const ViewParams &vp, const float *projected, const uint32_t *cum_tiles_hit,
                                  const uint32_t *num_visible, uint32_t cap, uint32_t *tile_ids, uint32_t *gids,
-                                 hipStream_t s) {
-    hipLaunchKernelGGL(k_map_intersects, dim3(walk_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, projected,
-                       cum_tiles_hit, num_visible, cap, tile_ids, gids);
+                                 const WalkWs &walk, hipStream_t s) {
+    const WalkQueue q = make_queue(walk);
+    hipLaunchKernelGGL(k_map_intersects, dim3(stride_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, projected,
+                       cum_tiles_hit, num_visible, cap, tile_ids, gids, q);
+    hipLaunchKernelGGL(k_walk_emit, dim3(1024), dim3(kThreads), 0, s, vp, projected, cum_tiles_hit, cap, tile_ids,
+                       gids, q);
     return hipGetLastError();
 }
 

@@ -57,6 +57,7 @@ struct FwdWs {
     uint32_t *tile_sorted;   // [cap]
     void *scan_ws;
     void *sort_ws;           // sized for max(N, cap)
+    WalkWs walk;             // (splat, chunk) queue of the tile walks
     size_t bytes;
 };
 
@@ -75,6 +76,11 @@ FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap) {
     f.tile_sorted = c.take<uint32_t>(cc);
     f.scan_ws = c.take<char>(scan_workspace_bytes(n));
     f.sort_ws = c.take<char>(sort_workspace_bytes(n > cap ? n : cap));
+    f.walk.capacity = (uint32_t)nn;
+    f.walk.counter = c.take<uint32_t>(1);
+    f.walk.items = c.take<uint32_t>(nn * 2);
+    f.walk.chunk_count = c.take<uint32_t>(nn);
+    f.walk.slot_of = c.take<uint32_t>(nn);
     f.bytes = c.bytes();
     return f;
 }
@@ -178,7 +184,7 @@ extern "C" int brush_render_forward(const BrushUniforms *h_uniforms, const float
     // uniforms buffer, counters, tile_bins = 0; ProjectSplats + order-preserving compaction
     // (render.rs:102-142)
     BRUSH_HIP_CHECK(launch_project_cull(vp, u, aux, num_tiles, means, log_scales, quats, ws.key_all,
-                                        ws.block_counts, ws.pre_keys, ws.pre_gids, s));
+                                        ws.block_counts, ws.pre_keys, ws.pre_gids, ws.walk.counter, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_CULL);
     // DepthSort: keys = f32 depth bits, all 32 bits (render.rs:151-156)
     BRUSH_HIP_CHECK(sort_launch(ws.pre_keys, ws.pre_gids, ws.sorted_keys, aux.global_from_compact_gid,
@@ -187,7 +193,7 @@ extern "C" int brush_render_forward(const BrushUniforms *h_uniforms, const float
     // ProjectVisible (render.rs:161-184)
     BRUSH_HIP_CHECK(launch_project_visible(vp, means, log_scales, quats, sh_coeffs, raw_opacity, aux.num_visible,
                                            aux.global_from_compact_gid, aux.compact_from_global_gid,
-                                           aux.projected_splats, ws.tiles_hit, s));
+                                           aux.projected_splats, ws.tiles_hit, ws.walk, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_VISIBLE);
     // PrefixSum over all N, tail treated as 0 (render.rs:186-192); total -> num_intersections
     BRUSH_HIP_CHECK(scan_launch(ws.tiles_hit, aux.cum_tiles_hit, n, aux.num_visible, aux.num_intersections, cap,
@@ -195,7 +201,7 @@ extern "C" int brush_render_forward(const BrushUniforms *h_uniforms, const float
     mark_fwd(s, 1 + BRUSH_STAGE_PREFIX_SUM);
     // MapGaussiansToIntersect (render.rs:211-223)
     BRUSH_HIP_CHECK(launch_map_intersects(vp, aux.projected_splats, aux.cum_tiles_hit, aux.num_visible, cap,
-                                          ws.tile_unsorted, ws.gid_unsorted, s));
+                                          ws.tile_unsorted, ws.gid_unsorted, ws.walk, s));
     mark_fwd(s, 1 + BRUSH_STAGE_MAP_INTERSECTS);
     // Tile sort on bits = 32 - clz(num_tiles) (render.rs:227-237)
     uint32_t bits = 0;
