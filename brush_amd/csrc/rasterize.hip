@@ -34,6 +34,18 @@ namespace {
 
 constexpr uint32_t kBatch = kWave;  // 64 splats per LDS batch, one per lane
 constexpr uint32_t kPix = 4;        // pixels per lane
+constexpr uint32_t kPairs = kPix / 2;
+
+// Pixels are processed in pairs held in float2 vectors: the arithmetic compiles to packed
+// v_pk_{mul,add,fma}_f32 (two pixels per VALU issue slot); only exp / rcp / min / compares /
+// selects stay per element.  Both raster kernels are VALU-issue bound.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat2(float v) { return (f2){v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 exp2_2(f2 v) { return (f2){__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
+__device__ __forceinline__ f2 min2(float lim, f2 v) { return (f2){fminf(lim, v.x), fminf(lim, v.y)}; }
+__device__ __forceinline__ f2 sel2(bool cx, bool cy, f2 a, f2 b) { return (f2){cx ? a.x : b.x, cy ? a.y : b.y}; }
+constexpr float kNegLog2e = -1.44269504088896341f;  // exp(-s) = exp2(kNegLog2e * s)
 
 struct SplatLds {
     float4 a[kBatch];  // xy.x, xy.y, conic.x, conic.y
@@ -79,20 +91,25 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32
     const float pcy = (float)py + 0.5f;  // rasterize.wgsl:32
     const float pcx0 = (float)px0 + 0.5f;
 
-    bool done[kPix];
-    float T[kPix], cr[kPix], cg[kPix], cb[kPix];
+    // Per-pair state: T (output transmittance), colour sums, last contributing isect; `live`
+    // is false once a pixel has saturated or lies outside the image.
+    bool live[kPix];
+    f2 T[kPairs], cr[kPairs], cg[kPairs], cb[kPairs];
     uint32_t fin[kPix];
 #pragma unroll
     for (uint32_t j = 0; j < kPix; j++) {
-        done[j] = !(px0 + j < w && py < h);
-        T[j] = 1.0f;
-        cr[j] = cg[j] = cb[j] = 0.0f;
+        live[j] = px0 + j < w && py < h;
         fin[j] = 0;
+    }
+#pragma unroll
+    for (uint32_t p = 0; p < kPairs; p++) {
+        T[p] = splat2(1.0f);
+        cr[p] = cg[p] = cb[p] = splat2(0.0f);
     }
 
     const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
     for (uint32_t batch_start = r0; batch_start < r1; batch_start += kBatch) {
-        if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+        if (__ballot(live[0] || live[1] || live[2] || live[3]) == 0ull) break;
         const uint32_t remaining = min(kBatch, r1 - batch_start);
         wave_sync();
         if (lane < remaining) {
@@ -109,25 +126,28 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32
             const float bdy = a.w * dy;
             const float dx0 = a.x - pcx0;
 #pragma unroll
-            for (uint32_t j = 0; j < kPix; j++) {
-                // Branch-free form of rasterize.wgsl:80-99 (selects, no exec-mask juggling).
-                const float dx = dx0 - (float)j;
-                const float sigma = 0.5f * (a.z * dx * dx + cdy2) + bdy * dx;
-                const float vis = __expf(-sigma);
-                const float alpha = fminf(0.999f, opac * vis);
-                const bool hit = !done[j] && sigma >= 0.0f && alpha >= 1.0f / 255.0f;
-                const float next_T = T[j] * (1.0f - alpha);
-                const bool stop = hit && next_T <= 1e-4f;  // :88-91: stop without adding this entry
-                const bool add = hit && !stop;
-                const float fac = alpha * T[j];
-                cr[j] = add ? __builtin_fmaf(b.y, fac, cr[j]) : cr[j];
-                cg[j] = add ? __builtin_fmaf(b.z, fac, cg[j]) : cg[j];
-                cb[j] = add ? __builtin_fmaf(b.w, fac, cb[j]) : cb[j];
-                T[j] = add ? next_T : T[j];
-                fin[j] = add ? batch_start + t : fin[j];
-                done[j] = done[j] || stop;
+            for (uint32_t p = 0; p < kPairs; p++) {
+                // rasterize.wgsl:80-99 for pixels 2p, 2p+1, branch-free
+                const f2 dx = splat2(dx0) - (f2){(float)(2 * p), (float)(2 * p + 1)};
+                const f2 sigma = fma2(splat2(0.5f), fma2(splat2(a.z) * dx, dx, splat2(cdy2)), splat2(bdy) * dx);
+                const f2 vis = exp2_2(sigma * kNegLog2e);
+                const f2 alpha = min2(0.999f, splat2(opac) * vis);
+                const f2 next_T = T[p] * (1.0f - alpha);
+                const bool hx = live[2 * p] && sigma.x >= 0.0f && alpha.x >= 1.0f / 255.0f;
+                const bool hy = live[2 * p + 1] && sigma.y >= 0.0f && alpha.y >= 1.0f / 255.0f;
+                const bool sx = hx && next_T.x <= 1e-4f, sy = hy && next_T.y <= 1e-4f;  // :88-91
+                const bool ax = hx && !sx, ay = hy && !sy;
+                const f2 fac = sel2(ax, ay, alpha * T[p], splat2(0.0f));
+                cr[p] = fma2(splat2(b.y), fac, cr[p]);
+                cg[p] = fma2(splat2(b.z), fac, cg[p]);
+                cb[p] = fma2(splat2(b.w), fac, cb[p]);
+                T[p] = sel2(ax, ay, next_T, T[p]);
+                fin[2 * p] = ax ? batch_start + t : fin[2 * p];
+                fin[2 * p + 1] = ay ? batch_start + t : fin[2 * p + 1];
+                live[2 * p] = live[2 * p] && !sx;
+                live[2 * p + 1] = live[2 * p + 1] && !sy;
             }
-            if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+            if (__ballot(live[0] || live[1] || live[2] || live[3]) == 0ull) break;
         }
     }
 
@@ -136,16 +156,20 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32
         for (uint32_t j = 0; j < kPix; j++) {
             if (px0 + j < w) {
                 const size_t pix = (size_t)(px0 + j) + (size_t)py * w;
-                const float al = 1.0f - T[j];
+                const float Tj = (j & 1) ? T[j / 2].y : T[j / 2].x;
+                const float rj = (j & 1) ? cr[j / 2].y : cr[j / 2].x;
+                const float gj = (j & 1) ? cg[j / 2].y : cg[j / 2].x;
+                const float bj = (j & 1) ? cb[j / 2].y : cb[j / 2].x;
+                const float al = 1.0f - Tj;
                 if (RASTER_U32) {
                     // rasterize.wgsl:106-109
-                    const uint32_t r8 = (uint32_t)fminf(fmaxf(cr[j] * 255.0f, 0.0f), 255.0f);
-                    const uint32_t g8 = (uint32_t)fminf(fmaxf(cg[j] * 255.0f, 0.0f), 255.0f);
-                    const uint32_t b8 = (uint32_t)fminf(fmaxf(cb[j] * 255.0f, 0.0f), 255.0f);
+                    const uint32_t r8 = (uint32_t)fminf(fmaxf(rj * 255.0f, 0.0f), 255.0f);
+                    const uint32_t g8 = (uint32_t)fminf(fmaxf(gj * 255.0f, 0.0f), 255.0f);
+                    const uint32_t b8 = (uint32_t)fminf(fmaxf(bj * 255.0f, 0.0f), 255.0f);
                     const uint32_t a8 = (uint32_t)fminf(fmaxf(al * 255.0f, 0.0f), 255.0f);
                     static_cast<uint32_t *>(out_img)[pix] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
                 } else {
-                    static_cast<float4 *>(out_img)[pix] = make_float4(cr[j], cg[j], cb[j], al);
+                    static_cast<float4 *>(out_img)[pix] = make_float4(rj, gj, bj, al);
                     final_index[pix] = fin[j];
                 }
             }
@@ -220,28 +244,31 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
     const float pcy = (float)py + 0.5f;
     const float pcx0 = (float)px0 + 0.5f;
 
-    bool inside[kPix];
-    // Per-pixel state.  The reference's running colour `buffer` (rasterize_backwards.wgsl:253-257)
-    // only ever appears dotted with the pixel's constant v_out.rgb, so the scalar
-    // D = sum_j fac_j * (c_j . v_rgb) carries the same information; K = T_final * v_out.a.
-    float T[kPix], K[kPix], D[kPix];
-    float4 vo[kPix];
-    uint32_t fin[kPix];
+    // Per-pixel state, kept per pixel pair.  The reference's running colour `buffer`
+    // (rasterize_backwards.wgsl:253-257) only ever appears dotted with the pixel's constant
+    // v_out.rgb, so the scalar D = sum_j fac_j * (c_j . v_rgb) carries the same information;
+    // K = T_final * v_out.a.  Pixels outside the image get fin = -1 so they never contribute.
+    f2 T[kPairs], K[kPairs], D[kPairs], vor[kPairs], vog[kPairs], vob[kPairs];
+    int32_t fin[kPix];
 #pragma unroll
     for (uint32_t j = 0; j < kPix; j++) {
-        inside[j] = px0 + j < w && py < h;
         float T_final = 1.0f;
-        fin[j] = 0;
-        vo[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (inside[j]) {
+        float4 vo = make_float4(0.f, 0.f, 0.f, 0.f);
+        fin[j] = -1;
+        if (px0 + j < w && py < h) {
             const size_t pix = (size_t)(px0 + j) + (size_t)py * w;
             T_final = 1.0f - out_img[pix * 4 + 3];  // rasterize_backwards.wgsl:163
-            fin[j] = final_index[pix];
-            vo[j] = reinterpret_cast<const float4 *>(v_out)[pix];
+            fin[j] = (int32_t)final_index[pix];
+            vo = reinterpret_cast<const float4 *>(v_out)[pix];
         }
-        T[j] = T_final;
-        K[j] = T_final * vo[j].w;
-        D[j] = 0.0f;
+        const uint32_t p = j / 2;
+        if (j & 1) {
+            T[p].y = T_final; K[p].y = T_final * vo.w; D[p].y = 0.0f;
+            vor[p].y = vo.x; vog[p].y = vo.y; vob[p].y = vo.z;
+        } else {
+            T[p].x = T_final; K[p].x = T_final * vo.w; D[p].x = 0.0f;
+            vor[p].x = vo.x; vog[p].x = vo.y; vob[p].x = vo.z;
+        }
     }
 
     // Batches walk the list back to front (rasterize_backwards.wgsl:194-208).
@@ -260,62 +287,67 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
         wave_sync();
 
         for (uint32_t t = 0; t < remaining; t++) {
-            const uint32_t isect_id = batch_end - 1u - t;
+            const int32_t isect_id = (int32_t)(batch_end - 1u - t);
             const float4 a = lds.a[t];
             const float4 b = lds.b[t];
             const float opac = lds.o[t];
             const float dy = a.y - pcy;
-            const float cdy2 = b.x * dy * dy;
+            const float dy2 = dy * dy;
+            const float cdy2 = b.x * dy2;
             const float bdy = a.w * dy;
             const float cdy = b.x * dy;
             const float dx0 = a.x - pcx0;
-            float g[kGradComps];
-#pragma unroll
-            for (uint32_t k = 0; k < kGradComps; k++) g[k] = 0.0f;
-            // Pass 1 (cheap, branch-free): alpha and the contribution mask of the 4 pixels.
-            float vis[kPix], alpha[kPix];
+            // Pass 1 (cheap): alpha and the contribution mask of the 4 pixels.
+            f2 dx[kPairs], vis[kPairs], alpha[kPairs];
             bool m[kPix];
 #pragma unroll
-            for (uint32_t j = 0; j < kPix; j++) {
-                const float dx = dx0 - (float)j;
-                const float sigma = 0.5f * (a.z * dx * dx + cdy2) + bdy * dx;
-                vis[j] = __expf(-sigma);
-                alpha[j] = fminf(0.99f, opac * vis[j]);  // 0.99 here (rasterize_backwards.wgsl:239)
-                m[j] = inside[j] && isect_id <= fin[j] && sigma >= 0.0f && alpha[j] >= 1.0f / 255.0f;
+            for (uint32_t p = 0; p < kPairs; p++) {
+                dx[p] = splat2(dx0) - (f2){(float)(2 * p), (float)(2 * p + 1)};
+                const f2 sigma = fma2(splat2(0.5f), fma2(splat2(a.z) * dx[p], dx[p], splat2(cdy2)), splat2(bdy) * dx[p]);
+                vis[p] = exp2_2(sigma * kNegLog2e);
+                alpha[p] = min2(0.99f, splat2(opac) * vis[p]);  // 0.99 here (rasterize_backwards.wgsl:239)
+                m[2 * p] = isect_id <= fin[2 * p] && sigma.x >= 0.0f && alpha[p].x >= 1.0f / 255.0f;
+                m[2 * p + 1] = isect_id <= fin[2 * p + 1] && sigma.y >= 0.0f && alpha[p].y >= 1.0f / 255.0f;
             }
             const bool any = __ballot(m[0] || m[1] || m[2] || m[3]) != 0ull;
-            // Pass 2: rasterize_backwards.wgsl:244-271 with selects; a pixel column no lane of the
+            // Pass 2: rasterize_backwards.wgsl:244-271 with selects; a pixel pair no lane of the
             // wave contributes to is skipped by a wave-uniform (scalar) branch.
+            f2 gs[kGradComps];
 #pragma unroll
-            for (uint32_t j = 0; j < kPix; j++) {
-                if (__ballot(m[j]) == 0ull) continue;
-                const float dx = dx0 - (float)j;
-                const float adx = a.z * dx;
+            for (uint32_t k = 0; k < kGradComps; k++) gs[k] = splat2(0.0f);
+#pragma unroll
+            for (uint32_t p = 0; p < kPairs; p++) {
+                const bool mx = m[2 * p], my = m[2 * p + 1];
+                if (__ballot(mx || my) == 0ull) continue;
                 // v_rcp_f32 (1 ulp) + one Newton step; 1 - alpha >= 0.01 so this is always finite.
-                const float om = 1.0f - alpha[j];
-                float ra = __builtin_amdgcn_rcpf(om);
-                ra = __builtin_fmaf(__builtin_fmaf(-om, ra, 1.0f), ra, ra);
-                const float Tn = T[j] * ra;
-                const float fac = alpha[j] * Tn;
-                // v_alpha = (c*T - buffer*ra) . v_rgb + T_final*ra*v_a  (rasterize_backwards.wgsl:253-254)
+                const f2 om = 1.0f - alpha[p];
+                f2 ra = (f2){__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                ra = fma2(fma2(-om, ra, splat2(1.0f)), ra, ra);
+                const f2 Tn = T[p] * ra;
+                const f2 fac = alpha[p] * Tn;
+                // v_alpha = (c*T - buffer*ra) . v_rgb + T_final*ra*v_a  (:253-254)
                 //         = T*(c . v_rgb) + ra*(K - D)
-                const float cv = b.y * vo[j].x + b.z * vo[j].y + b.w * vo[j].z;
-                const float v_alpha = __builtin_fmaf(Tn, cv, ra * (K[j] - D[j]));
-                T[j] = m[j] ? Tn : T[j];
-                D[j] = m[j] ? __builtin_fmaf(fac, cv, D[j]) : D[j];
-                const float vis_m = m[j] ? vis[j] * v_alpha : 0.0f;  // v_opac term
-                const float v_sigma = -opac * vis_m;                  // 0 when masked
-                const float fac_m = m[j] ? fac : 0.0f;
-                g[0] = __builtin_fmaf(v_sigma, adx + bdy, g[0]);
-                g[1] = __builtin_fmaf(v_sigma, a.w * dx + cdy, g[1]);
-                g[2] = __builtin_fmaf(0.5f * v_sigma, dx * dx, g[2]);
-                g[3] = __builtin_fmaf(v_sigma, dx * dy, g[3]);
-                g[4] = __builtin_fmaf(0.5f * v_sigma, dy * dy, g[4]);
-                g[5] = __builtin_fmaf(fac_m, vo[j].x, g[5]);
-                g[6] = __builtin_fmaf(fac_m, vo[j].y, g[6]);
-                g[7] = __builtin_fmaf(fac_m, vo[j].z, g[7]);
-                g[8] += vis_m;
+                const f2 cv = fma2(splat2(b.w), vob[p], fma2(splat2(b.z), vog[p], splat2(b.y) * vor[p]));
+                const f2 v_alpha = fma2(Tn, cv, ra * (K[p] - D[p]));
+                T[p] = sel2(mx, my, Tn, T[p]);
+                D[p] = sel2(mx, my, fma2(fac, cv, D[p]), D[p]);
+                const f2 vis_m = sel2(mx, my, vis[p] * v_alpha, splat2(0.0f));  // v_opac term
+                const f2 v_sigma = vis_m * (-opac);                             // 0 when masked
+                const f2 fac_m = sel2(mx, my, fac, splat2(0.0f));
+                const f2 hs = v_sigma * 0.5f;
+                gs[0] = fma2(v_sigma, fma2(splat2(a.z), dx[p], splat2(bdy)), gs[0]);
+                gs[1] = fma2(v_sigma, fma2(splat2(a.w), dx[p], splat2(cdy)), gs[1]);
+                gs[2] = fma2(hs, dx[p] * dx[p], gs[2]);
+                gs[3] = fma2(v_sigma, dx[p] * dy, gs[3]);
+                gs[4] = fma2(hs, splat2(dy2), gs[4]);
+                gs[5] = fma2(fac_m, vor[p], gs[5]);
+                gs[6] = fma2(fac_m, vog[p], gs[6]);
+                gs[7] = fma2(fac_m, vob[p], gs[7]);
+                gs[8] += vis_m;
             }
+            float g[kGradComps];
+#pragma unroll
+            for (uint32_t k = 0; k < kGradComps; k++) g[k] = gs[k].x + gs[k].y;
             if (any) {  // wave-uniform: all 64 lanes take part in the reduction
                 // 8 components: two transposing folds (lane-swap + add), then a row-of-16 scan of
                 // the two survivors; component 8 takes the plain 6-step DPP sum.  26 VALU ops.
