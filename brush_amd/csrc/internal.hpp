@@ -12,6 +12,7 @@ struct WalkWs {
     uint32_t *counter;      // [1]
     uint32_t *items;        // [capacity * 2]
     uint32_t *chunk_count;  // [capacity]
+    uint32_t *chunk_mask;   // [capacity * 8] (four 64-bit hit masks per item)
     uint32_t *slot_of;      // [N]
     uint32_t capacity;
 };

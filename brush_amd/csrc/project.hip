@@ -44,15 +44,27 @@ struct WalkQueue {
     uint32_t *counter;      // [1] items reserved so far (zeroed by the cull kernel)
     uint2 *items;           // [capacity] (compact gid, chunk index)
     uint32_t *chunk_count;  // [capacity] tiles hit inside the chunk (written by the count pass)
-    uint32_t *slot_of;      // [N] first item slot of a queued splat, kInvalid if walked inline
+    uint64_t *chunk_mask;   // [capacity][4] hit bitmask of the chunk's 256 tiles (count pass -> emit pass)
+    uint32_t *slot_of;      // [N] queued splat: first item slot (< 2^31); inline splat:
+                            //     kInlineFlag | hit mask of its <= 8 bbox tiles, or kInlineRetest
     uint32_t capacity;
 };
+// The count pass records WHICH tiles passed, so the emit pass never repeats the exact test.
+constexpr uint32_t kInlineFlag = 0x80000000u;
+constexpr uint32_t kInlineRetest = 0xFFFFFFFFu;  // walked inline because the queue was full
 
-__device__ __forceinline__ uint32_t walk_inline_count(const uint32_t bb[4], const TileTest &tt, const float xy[2]) {
-    uint32_t cnt = 0;
+// Returns the hit mask of a small bbox (bit i = i-th tile in row-major order); for larger bboxes
+// (queue-full fallback) only the count is meaningful.
+__device__ __forceinline__ uint32_t walk_inline_count(const uint32_t bb[4], const TileTest &tt, const float xy[2],
+                                                      uint32_t &mask) {
+    uint32_t cnt = 0, i = 0;
+    mask = 0;
     for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
-        for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
-            if (can_be_visible(tt, tx, ty, xy)) cnt++;
+        for (uint32_t tx = bb[0]; tx < bb[2]; tx++, i++)
+            if (can_be_visible(tt, tx, ty, xy)) {
+                cnt++;
+                if (i < 31) mask |= 1u << i;
+            }
     return cnt;
 }
 
@@ -287,7 +299,11 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
                 for (uint32_t k = 0; k < nchunks; k++) q.items[first + k] = make_uint2(c, k);
             }
         }
-        if (slot == kInvalid) area = walk_inline_count(bb, tt, xy);
+        if (slot == kInvalid) {
+            uint32_t mask;
+            area = walk_inline_count(bb, tt, xy, mask);
+            slot = bbox_tiles <= kSmallArea ? (kInlineFlag | mask) : kInlineRetest;
+        }
         q.slot_of[c] = slot;
         if (active) {
             float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
@@ -316,11 +332,15 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
         const SplatWalk s = load_walk(vp, projected, item.x);
         const uint32_t lo = item.y * kChunkTiles, hi = min(s.area, lo + kChunkTiles);
         uint32_t cnt = 0;
-        for (uint32_t i0 = lo; i0 < hi; i0 += kWave) {
+        uint64_t my_mask = 0;  // lane k keeps the ballot of step k
+        for (uint32_t i0 = lo, step = 0; i0 < hi; i0 += kWave, step++) {
             const uint32_t i = i0 + lane;
             const bool hit = i < hi && can_be_visible(s.tt, s.b0 + i % s.bw, s.b1 + i / s.bw, s.xy);
-            cnt += __popcll(__ballot(hit));
+            const uint64_t bal = __ballot(hit);
+            cnt += __popcll(bal);
+            if (lane == step) my_mask = bal;
         }
+        if (lane < kChunkTiles / kWave) q.chunk_mask[(size_t)it * (kChunkTiles / kWave) + lane] = my_mask;
         if (lane == 0) {
             q.chunk_count[it] = cnt;
             if (cnt) atomicAdd(&tiles_hit[item.x], cnt);
@@ -338,16 +358,32 @@ __global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, cons
                                                              uint32_t *__restrict__ gids, WalkQueue q) {
     const uint32_t V = *num_visible;
     for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < V; c += gridDim.x * kThreads) {
-        if (q.slot_of[c] != kInvalid) continue;
+        const uint32_t code = q.slot_of[c];
+        if (!(code & kInlineFlag)) continue;  // queued: emitted by k_walk_emit
         const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
         const float xy[2] = {p[0], p[1]};
         const float conic[3] = {p[2], p[3], p[4]};
         const uint32_t radius = radius_from_conic(conic);
         uint32_t bb[4];
         get_tile_bbox(xy, radius, vp.tile_bounds, bb);
-        const TileTest tt = make_tile_test(conic, p[8]);
-        const uint32_t isect = c > 0 ? cum_tiles_hit[c - 1] : 0u;
-        walk_inline_emit(bb, tt, xy, c, isect, vp.tile_bounds[0], cap, tile_ids, gids);
+        uint32_t isect = c > 0 ? cum_tiles_hit[c - 1] : 0u;
+        if (code == kInlineRetest) {
+            const TileTest tt = make_tile_test(conic, p[8]);
+            walk_inline_emit(bb, tt, xy, c, isect, vp.tile_bounds[0], cap, tile_ids, gids);
+        } else {
+            // replay the hit mask recorded by project_visible (row-major over the bbox)
+            const uint32_t bw = bb[2] - bb[0];
+            uint32_t mask = code & ~kInlineFlag;
+            while (mask) {
+                const uint32_t i = __ffs((int)mask) - 1;
+                mask &= mask - 1;
+                if (isect < cap) {
+                    tile_ids[isect] = (bb[0] + i % bw) + (bb[1] + i / bw) * vp.tile_bounds[0];
+                    gids[isect] = c;
+                    isect++;
+                }
+            }
+        }
     }
 }
 
@@ -369,21 +405,22 @@ __global__ __launch_bounds__(kThreads) void k_walk_emit(ViewParams vp, const flo
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
         uint32_t run = (c > 0 ? cum_tiles_hit[c - 1] : 0u) + before;
-        const SplatWalk s = load_walk(vp, projected, c);
-        const uint32_t lo = k * kChunkTiles, hi = min(s.area, lo + kChunkTiles);
-        for (uint32_t i0 = lo; i0 < hi; i0 += kWave) {
+        // bbox geometry only (no tile tests): replay the recorded hit masks in order
+        const float *pp = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
+        const float xy[2] = {pp[0], pp[1]};
+        const float conic[3] = {pp[2], pp[3], pp[4]};
+        uint32_t bb[4];
+        get_tile_bbox(xy, radius_from_conic(conic), vp.tile_bounds, bb);
+        const uint32_t bw = bb[2] - bb[0];
+        const uint32_t area = bw * (bb[3] - bb[1]);
+        const uint32_t lo = k * kChunkTiles, hi = min(area, lo + kChunkTiles);
+        for (uint32_t i0 = lo, step = 0; i0 < hi; i0 += kWave, step++) {
             const uint32_t i = i0 + lane;
-            uint32_t tx = 0, ty = 0;
-            bool hit = false;
-            if (i < hi) {
-                tx = s.b0 + i % s.bw;
-                ty = s.b1 + i / s.bw;
-                hit = can_be_visible(s.tt, tx, ty, s.xy);
-            }
-            const uint64_t bal = __ballot(hit);
+            const uint64_t bal = q.chunk_mask[(size_t)it * (kChunkTiles / kWave) + step];
+            const bool hit = (bal >> lane) & 1ull;
             const uint32_t pos = run + __popcll(bal & lt);
             if (hit && pos < cap) {
-                tile_ids[pos] = tx + ty * vp.tile_bounds[0];
+                tile_ids[pos] = (bb[0] + i % bw) + (bb[1] + i / bw) * vp.tile_bounds[0];
                 gids[pos] = c;
             }
             run += __popcll(bal);
@@ -418,6 +455,7 @@ WalkQueue make_queue(const WalkWs &w) {
     q.counter = w.counter;
     q.items = reinterpret_cast<uint2 *>(w.items);
     q.chunk_count = w.chunk_count;
+    q.chunk_mask = reinterpret_cast<uint64_t *>(w.chunk_mask);
     q.slot_of = w.slot_of;
     q.capacity = w.capacity;
     return q;

@@ -271,8 +271,18 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
         }
     }
 
+    // Entries behind the last one any pixel of this tile composited (isect id > max final_index)
+    // fail `isect_id <= final_isect` for every pixel (rasterize_backwards.wgsl:229), so the walk
+    // starts at the tile's largest final index instead of the end of the list.  Exact, and in
+    // saturated scenes it removes almost the whole list (the forward stopped early there too).
+    int32_t max_fin = max(max(fin[0], fin[1]), max(fin[2], fin[3]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) max_fin = max(max_fin, __shfl_xor(max_fin, d, 64));
+    const uint32_t walk_end = min(r1, (uint32_t)(max_fin + 1));
+    if (walk_end <= r0) return;
+
     // Batches walk the list back to front (rasterize_backwards.wgsl:194-208).
-    for (uint32_t batch_end = r1; batch_end > r0;) {
+    for (uint32_t batch_end = walk_end; batch_end > r0;) {
         const uint32_t remaining = min(kBatch, batch_end - r0);
         wave_sync();  // previous batch fully flushed
         if (lane < remaining) {

@@ -80,6 +80,7 @@ FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap) {
     f.walk.counter = c.take<uint32_t>(1);
     f.walk.items = c.take<uint32_t>(nn * 2);
     f.walk.chunk_count = c.take<uint32_t>(nn);
+    f.walk.chunk_mask = c.take<uint32_t>(nn * 8);
     f.walk.slot_of = c.take<uint32_t>(nn);
     f.bytes = c.bytes();
     return f;
