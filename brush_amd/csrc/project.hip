@@ -292,12 +292,21 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
         const uint32_t bbox_tiles = (bb[2] - bb[0]) * (bb[3] - bb[1]);
         uint32_t area = 0, slot = kInvalid;
         if (bbox_tiles > kSmallArea) {
+            // Reserve nchunks consecutive slots.  A CAS loop (not atomicAdd) so that a reservation
+            // that does not fit leaves the counter untouched: every slot below *counter is then
+            // guaranteed to be written, which the consumer kernels rely on.
             const uint32_t nchunks = (bbox_tiles + kChunkTiles - 1) / kChunkTiles;
-            const uint32_t first = atomicAdd(q.counter, nchunks);
-            if (first + nchunks <= q.capacity) {
-                slot = first;
-                for (uint32_t k = 0; k < nchunks; k++) q.items[first + k] = make_uint2(c, k);
+            uint32_t seen = *reinterpret_cast<volatile uint32_t *>(q.counter);
+            while (seen + nchunks <= q.capacity) {
+                const uint32_t prev = atomicCAS(q.counter, seen, seen + nchunks);
+                if (prev == seen) {
+                    slot = seen;
+                    break;
+                }
+                seen = prev;
             }
+            if (slot != kInvalid)
+                for (uint32_t k = 0; k < nchunks; k++) q.items[slot + k] = make_uint2(c, k);
         }
         if (slot == kInvalid) {
             uint32_t mask;

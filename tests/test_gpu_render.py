@@ -29,11 +29,12 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _camera(w, h):
+def _camera(w, h, position=None, rotation_xyzw=None, center_uv=None):
     import brush_amd
 
     c = H.reference_test_camera(w, h)
-    return brush_amd.Camera(c["position"], c["rotation_xyzw"], c["fov_x"], c["fov_y"], c["center_uv"])
+    return brush_amd.Camera(position or c["position"], rotation_xyzw or c["rotation_xyzw"], c["fov_x"], c["fov_y"],
+                            center_uv or c["center_uv"])
 
 
 def _t(a, dev, grad=False):
@@ -108,7 +109,7 @@ def test_renders_at_all(dev):
         assert not bool(p.grad.any())
 
 
-def _run_pair(dev, cloud, w, h, sh_degree, max_intersects=None, v_out=None):
+def _run_pair(dev, cloud, w, h, sh_degree, max_intersects=None, v_out=None, camera=None):
     """Run the GPU op and the oracle on identical inputs (the oracle gets the uniform words the
     GPU op actually used).  Returns (gpu dict, oracle dict)."""
     import torch
@@ -118,7 +119,7 @@ def _run_pair(dev, cloud, w, h, sh_degree, max_intersects=None, v_out=None):
 
     params = {k: _t(cloud[k], dev, grad=True) for k in ("means", "log_scales", "quats", "sh", "raw_opac")}
     xy = torch.zeros((cloud["means"].shape[0], 2), device=dev, requires_grad=True)
-    out, aux = brush_amd.render_splats(_camera(w, h), (w, h), params["means"], xy, params["log_scales"],
+    out, aux = brush_amd.render_splats(camera or _camera(w, h), (w, h), params["means"], xy, params["log_scales"],
                                        params["quats"], params["sh"], params["raw_opac"], False, max_intersects)
     u = uniforms_to_numpy(aux)
     o_out, o_aux = O.render_forward(u, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["sh"],
@@ -220,6 +221,81 @@ def test_matches_oracle(dev, n, w, h, deg, mult):
     gpu, orc = _run_pair(dev, cloud, w, h, deg, max_intersects=4_000_000)
     V, I = _assert_forward_parity(gpu, orc, w, h)
     assert V > 0 and I > 0
+    _assert_grad_parity(gpu, orc)
+
+
+def test_rotated_off_centre_camera(dev):
+    """Non-identity world->camera rotation, translated eye, principal point off centre: exercises every
+    element of the 28-word uniforms (viewmat columns, pixel_center) against the oracle."""
+    q = np.array([0.12, -0.31, 0.07, 0.0])
+    q[3] = np.sqrt(1.0 - (q[:3] ** 2).sum())
+    cam = _camera(200, 120, position=[1.5, -0.7, -6.0], rotation_xyzw=q.tolist(), center_uv=(0.43, 0.58))
+    cloud = H.synthetic_cloud(20000, 2, seed=11, mean_mult=0.01)
+    gpu, orc = _run_pair(dev, cloud, 200, 120, 2, camera=cam)
+    V, I = _assert_forward_parity(gpu, orc, 200, 120)
+    assert V > 1000 and I > V
+    _assert_grad_parity(gpu, orc)
+
+
+def test_alpha_clamp_quirk(dev):
+    """Opacities ~1: alpha reaches the 0.999 forward clamp but the backward clamps at 0.99
+    (rasterize.wgsl:83 vs rasterize_backwards.wgsl:239).  The GPU must reproduce that mismatch: the
+    oracle follows the WGSL text, and a backward using 0.999 would be off by far more than the
+    tolerance on the saturated pixels."""
+    cloud = H.synthetic_cloud(3000, 0, seed=21, mean_mult=0.002)
+    cloud["raw_opac"][:] = 12.0  # sigmoid -> 0.999994
+    gpu, orc = _run_pair(dev, cloud, 160, 96, 0)
+    _assert_forward_parity(gpu, orc, 160, 96)
+    proj = orc["aux"]["projected_splats"][: int(orc["aux"]["num_visible"][0])]
+    assert (proj[:, 8] > 0.9999).all()
+    _assert_grad_parity(gpu, orc)
+    # sanity: the quirk is active (a 0.999-clamped backward differs visibly from the 0.99 one)
+    assert np.abs(orc["grads"]["v_opac"]).max() > 0
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 65])
+def test_tiny_and_empty_inputs(dev, n):
+    """Empty and ragged splat counts (the reference allocates [0,..] tensors without complaint)."""
+    import torch
+
+    import brush_amd
+
+    cloud = H.synthetic_cloud(max(n, 1), 1, seed=5, mean_mult=0.0005)
+    cloud = {k: v[:n] for k, v in cloud.items()}
+    if n == 0:
+        p = {k: _t(v, dev, grad=True) for k, v in cloud.items()}
+        out, aux = brush_amd.render_splats(_camera(64, 48), (64, 48), p["means"], None, p["log_scales"], p["quats"],
+                                           p["sh"], p["raw_opac"])
+        assert aux.read_num_visible() == 0 and aux.read_num_intersections() == 0
+        assert not bool(out.any())
+        out.sum().backward()
+        assert all(v.grad is not None and v.grad.numel() == 0 for v in p.values())
+        assert not bool(aux.tile_bins.any())
+        return
+    gpu, orc = _run_pair(dev, cloud, 64, 48, 1)
+    _assert_forward_parity(gpu, orc, 64, 48)
+    _assert_grad_parity(gpu, orc)
+
+
+def test_walk_queue_overflow_falls_back_inline(dev):
+    """A handful of whole-screen splats need far more (splat, chunk) work items than the queue
+    holds (capacity = N): the overflowing splats are walked inline and the result is unchanged."""
+    n, w, h = 100, 1920, 1080  # 32 chunks per splat: only the first 3 reservations fit in 100 slots
+    cloud = H.synthetic_cloud(n, 0, seed=2, mean_mult=0.0001)
+    cloud["means"][:, 2] = np.linspace(-7.5, -6.5, n).astype(np.float32)  # 0.5..1.5 in front of the eye
+    cloud["log_scales"][:] = np.log(4.0)
+    gpu, orc = _run_pair(dev, cloud, w, h, 0, max_intersects=1_000_000)
+    V, I = _assert_forward_parity(gpu, orc, w, h)
+    assert V == n and I > 8160 * 8  # most splats cover the whole 120x68 tile grid
+    _assert_grad_parity(gpu, orc)
+
+
+def test_4k_frame(dev):
+    """3840x2160 (240x135 tiles, 15-bit tile ids -> 16 sorted bits, SURVEY §8 c5 resolution)."""
+    cloud = H.synthetic_cloud(120000, 0, seed=4, mean_mult=1.0)
+    gpu, orc = _run_pair(dev, cloud, 3840, 2160, 0, max_intersects=3_000_000)
+    V, I = _assert_forward_parity(gpu, orc, 3840, 2160)
+    assert V > 5000 and I > V
     _assert_grad_parity(gpu, orc)
 
 
