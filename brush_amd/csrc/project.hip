@@ -215,6 +215,7 @@ __global__ __launch_bounds__(kThreads) void k_compact(uint32_t n, const uint32_t
 // project_visible.wgsl:163-258.  One visible splat per lane (compact = depth order), gathers
 // its parameters by global id; writes ProjectedSplat (36 B), the exact tile count, and the
 // inverse map.  Lanes c >= V clear the tail of global_from_compact_gid.
+template <int DEG>
 __global__ __launch_bounds__(kThreads) void k_project_visible(
     ViewParams vp, const float *__restrict__ means, const float *__restrict__ log_scales,
     const float *__restrict__ quats, const float *__restrict__ sh_coeffs, const float *__restrict__ raw_opac,
@@ -223,12 +224,14 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
     WalkQueue q) {
     const uint32_t V = *num_visible;
     const uint32_t n = vp.total_splats;
-    const uint32_t ncoef = (vp.sh_degree + 1) * (vp.sh_degree + 1);
+    constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);  // compile-time: all SH loads issue together
     // Tail of global_from_compact_gid (never written by the sort) := 0.
     for (uint32_t i = V + blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
         global_from_compact[i] = 0;
-    for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < V; c += gridDim.x * kThreads) {
-        const bool active = true;
+    // Block-uniform trip count: the queue reservation below is a wave-level collective.
+    for (uint32_t base = blockIdx.x * kThreads; base < V; base += gridDim.x * kThreads) {
+        const uint32_t c = base + threadIdx.x;
+        const bool active = c < V;
         float xy[2] = {0.f, 0.f}, conic[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
         float opac = 0.f;
         uint32_t bb[4] = {0, 0, 0, 0};
@@ -253,30 +256,30 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
             // SH -> colour, evaluated with the WGSL expression tree (project_visible.wgsl:51-147).
             float dir[3];
             view_dir(vp, mean, dir);
-            float Y[25];
-            sh_basis<25>(vp.sh_degree, dir, Y);
+            float Y[ncoef];
+            sh_basis<ncoef>(DEG, dir, Y);
             const float *sh = sh_coeffs + (size_t)g * ncoef * 3;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 float col = Y[0] * sh[ch];
-                if (vp.sh_degree >= 1) {
+                if (DEG >= 1) {
                     const float inner =
                         ((-dir[1]) * sh[1 * 3 + ch] + dir[2] * sh[2 * 3 + ch]) - dir[0] * sh[3 * 3 + ch];
                     col = col + 0.48860251190292f * inner;
                 }
-                if (vp.sh_degree >= 2) {
+                if (DEG >= 2) {
                     float acc = Y[4] * sh[4 * 3 + ch];
 #pragma unroll
                     for (int k = 5; k < 9; k++) acc = acc + Y[k] * sh[k * 3 + ch];
                     col = col + acc;
                 }
-                if (vp.sh_degree >= 3) {
+                if (DEG >= 3) {
                     float acc = Y[9] * sh[9 * 3 + ch];
 #pragma unroll
                     for (int k = 10; k < 16; k++) acc = acc + Y[k] * sh[k * 3 + ch];
                     col = col + acc;
                 }
-                if (vp.sh_degree >= 4) {
+                if (DEG >= 4) {
                     float acc = Y[16] * sh[16 * 3 + ch];
 #pragma unroll
                     for (int k = 17; k < 25; k++) acc = acc + Y[k] * sh[k * 3 + ch];
@@ -288,32 +291,36 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
             get_tile_bbox(xy, radius, vp.tile_bounds, bb);
             tt = make_tile_test(conic, opac);
         }
-        // exact tile count (project_visible.wgsl:244-250): inline for small bboxes, queued otherwise
-        const uint32_t bbox_tiles = (bb[2] - bb[0]) * (bb[3] - bb[1]);
-        uint32_t area = 0, slot = kInvalid;
-        if (bbox_tiles > kSmallArea) {
-            // Reserve nchunks consecutive slots.  A CAS loop (not atomicAdd) so that a reservation
-            // that does not fit leaves the counter untouched: every slot below *counter is then
-            // guaranteed to be written, which the consumer kernels rely on.
-            const uint32_t nchunks = (bbox_tiles + kChunkTiles - 1) / kChunkTiles;
-            uint32_t seen = *reinterpret_cast<volatile uint32_t *>(q.counter);
-            while (seen + nchunks <= q.capacity) {
-                const uint32_t prev = atomicCAS(q.counter, seen, seen + nchunks);
-                if (prev == seen) {
-                    slot = seen;
-                    break;
-                }
-                seen = prev;
-            }
-            if (slot != kInvalid)
-                for (uint32_t k = 0; k < nchunks; k++) q.items[slot + k] = make_uint2(c, k);
+        // exact tile count (project_visible.wgsl:244-250): inline for small bboxes, queued otherwise.
+        // Queue slots are reserved with ONE atomicAdd per wave (wave scan of the chunk counts); a
+        // per-lane atomic on the single counter serialises tens of thousands of requests.
+        const uint32_t bbox_tiles = active ? (bb[2] - bb[0]) * (bb[3] - bb[1]) : 0u;
+        const uint32_t nchunks = bbox_tiles > kSmallArea ? (bbox_tiles + kChunkTiles - 1) / kChunkTiles : 0u;
+        const uint32_t incl = wave_inclusive_scan(nchunks);
+        const uint32_t wave_total = __shfl(incl, 63, 64);
+        uint32_t wave_base = 0;
+        if (wave_total) {
+            if (lane_id() == 0) wave_base = atomicAdd(q.counter, wave_total);
+            wave_base = __shfl(wave_base, 0, 64);
         }
-        if (slot == kInvalid) {
+        uint32_t area = 0, slot = kInvalid;
+        if (nchunks) {
+            const uint32_t first = wave_base + incl - nchunks;
+            if (first + nchunks <= q.capacity) {
+                slot = first;
+                for (uint32_t k = 0; k < nchunks; k++) q.items[first + k] = make_uint2(c, k);
+            } else {
+                // Does not fit: walk inline.  Reservations are disjoint, so at most one of them
+                // straddles the capacity; its in-range slots get a sentinel the consumers skip.
+                for (uint32_t k = first; k < q.capacity; k++) q.items[k] = make_uint2(kInvalid, 0u);
+            }
+        }
+        if (active && slot == kInvalid) {
             uint32_t mask;
             area = walk_inline_count(bb, tt, xy, mask);
             slot = bbox_tiles <= kSmallArea ? (kInlineFlag | mask) : kInlineRetest;
         }
-        q.slot_of[c] = slot;
+        if (active) q.slot_of[c] = slot;
         if (active) {
             float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
             p[0] = xy[0];
@@ -338,6 +345,7 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
     const uint32_t waves = gridDim.x * (kThreads / kWave);
     for (uint32_t it = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; it < n_items; it += waves) {
         const uint2 item = q.items[it];
+        if (item.x == kInvalid) continue;  // hole left by a reservation that straddled the capacity
         const SplatWalk s = load_walk(vp, projected, item.x);
         const uint32_t lo = item.y * kChunkTiles, hi = min(s.area, lo + kChunkTiles);
         uint32_t cnt = 0;
@@ -408,6 +416,7 @@ __global__ __launch_bounds__(kThreads) void k_walk_emit(ViewParams vp, const flo
     const uint32_t waves = gridDim.x * (kThreads / kWave);
     for (uint32_t it = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; it < n_items; it += waves) {
         const uint2 item = q.items[it];
+        if (item.x == kInvalid) continue;
         const uint32_t c = item.x, k = item.y;
         uint32_t before = 0;
         for (uint32_t j = lane; j < k; j += kWave) before += q.chunk_count[it - k + j];
@@ -498,9 +507,18 @@ hipError_t launch_project_visible(const ViewParams &vp, const float *means, cons
                                   uint32_t *compact_from_global, float *projected, uint32_t *tiles_hit,
                                   const WalkWs &walk, hipStream_t s) {
     const WalkQueue q = make_queue(walk);
-    hipLaunchKernelGGL(k_project_visible, dim3(stride_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, means,
-                       log_scales, quats, sh, raw_opac, num_visible, global_from_compact, compact_from_global,
-                       projected, tiles_hit, q);
+    const dim3 grid(stride_grid(vp.total_splats)), block(kThreads);
+#define BRUSH_LAUNCH_PV(D)                                                                                  \
+    hipLaunchKernelGGL(k_project_visible<D>, grid, block, 0, s, vp, means, log_scales, quats, sh, raw_opac, \
+                       num_visible, global_from_compact, compact_from_global, projected, tiles_hit, q)
+    switch (vp.sh_degree) {
+        case 0: BRUSH_LAUNCH_PV(0); break;
+        case 1: BRUSH_LAUNCH_PV(1); break;
+        case 2: BRUSH_LAUNCH_PV(2); break;
+        case 3: BRUSH_LAUNCH_PV(3); break;
+        default: BRUSH_LAUNCH_PV(4); break;
+    }
+#undef BRUSH_LAUNCH_PV
     hipLaunchKernelGGL(k_walk_count, dim3(1024), dim3(kThreads), 0, s, vp, projected, q, tiles_hit);
     return hipGetLastError();
 }
