@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=20, help="extra steps with stage events (untimed)")
+    ap.add_argument("--train-steps", type=int, default=20,
+                    help="extra (untimed for `value`) steps of the full training iteration: loss + Adam groups")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every launch from the host instead of replaying one captured hipGraph per step")
     return ap.parse_args()
@@ -192,9 +194,53 @@ def main():
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(stage_ms[dominant], 5)}
+    # Device-to-device copy bandwidth measured in the same run: 1 GiB read + 1 GiB write.
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
     B = algorithmic_bytes(n, V, I, P, T, C)
     whole_path = {"algorithmic_bytes": int(B), "achieved_GBs": round(B / (ms_per_step * 1e-3) / 1e9, 2),
-                  "frac_of_hbm_peak": round(B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                  "frac_of_hbm_peak": round(B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                  "measured_copy_GBs": round(copy_gbs, 1)}
+
+    # ---- full training iteration: render + L1/SSIM loss + backward + 5 Adam groups
+    train = None
+    if args.train_steps > 0:
+        splats = brush_amd.Splats(p["means"], p["sh"], p["quats"], p["raw_opac"], p["log_scales"])
+        trainer = brush_amd.SplatTrainer(splats, brush_amd.TrainConfig(warmup_steps=0))
+        gt = torch.rand((h, w, 3), dtype=torch.float32, device=dev)  # synthetic target image
+
+        def sync(grads):
+            if world > 1:
+                for g_ in grads:
+                    dist.all_reduce(g_)
+
+        for _ in range(3):
+            trainer.step(splats, cam, gt, 1.0, world, sync)
+        barrier()
+        tt = time.perf_counter()
+        for _ in range(args.train_steps):
+            trainer.step(splats, cam, gt, 1.0, world, sync)
+        barrier()
+        tsec = time.perf_counter() - tt
+        if world > 1:
+            t = torch.tensor([tsec], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tsec = float(t.item())
+        train = {"iters_per_s": round(args.train_steps / tsec, 2), "ms_per_iter": round(tsec * 1e3 / args.train_steps, 4),
+                 "views_per_iter": n_gpus, "steps": args.train_steps,
+                 "what": "render + L1*0.8-SSIM*0.2 loss + backward + 5 Adam groups (train.rs:211-359), no refinement, "
+                         "eager PyTorch around the HIP op"}
+        del splats, trainer, gt
 
     # ---- CPU baseline: the oracle (a port), rank 0, N=1 only --------------------------------
     cpu_baseline = None
@@ -227,7 +273,7 @@ def main():
                        "launch": "eager" if graph is None else "hipGraph replay of one fwd+bwd",
                        "num_visible": V, "num_intersections": I, "max_intersects": aux.max_intersects,
                        "overflow": overflow},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "whole_path": whole_path,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "whole_path": whole_path, "train": train,
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         }
         print(json.dumps(line), flush=True)

@@ -18,5 +18,6 @@ from .render import RenderAux, render_splats, sh_coeffs_for_degree, sh_degree_fr
 from .sort import radix_argsort  # noqa: F401
 from .prefix_sum import prefix_sum  # noqa: F401
 from .gaussian_splats import Splats  # noqa: F401
+from .train import SplatTrainer, TrainConfig  # noqa: F401
 
 __version__ = "0.1.0"

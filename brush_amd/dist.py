@@ -49,12 +49,11 @@ def densification_stats(v_xy: torch.Tensor, aux: RenderAux, img_size) -> torch.T
     scale = torch.tensor([w / 2.0, h / 2.0], dtype=v_xy.dtype, device=v_xy.device)
     norm = torch.sqrt(torch.sum((v_xy * scale) ** 2, dim=1))
     n = v_xy.shape[0]
-    # xy_grad_counts.select_assign(0, gs_ids, arange(N) < num_visible): the tail of gs_ids is 0 in
-    # this build and carries a 0 mask, so it never marks a splat visible.
-    valid = (torch.arange(n, device=v_xy.device) < aux.num_visible.to(torch.int64)).to(v_xy.dtype)
-    visible = torch.zeros(n, dtype=v_xy.dtype, device=v_xy.device)
-    visible.index_put_((aux.global_from_compact_gid[:n].long(),), valid, accumulate=True)
-    return torch.stack([norm, visible.clamp_(max=1.0)])
+    # The reference scatters `arange(N) < num_visible` through global_from_compact_gid
+    # (xy_grad_counts.select_assign, train.rs:306-312); the inverse map of this build gives the
+    # same visibility mask without a scatter.
+    visible = (aux.compact_from_global_gid[:n] >= 0).to(v_xy.dtype)
+    return torch.stack([norm, visible])
 
 
 def allreduce_densification_stats(stats: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:

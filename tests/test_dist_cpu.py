@@ -51,6 +51,13 @@ def _oracle_block(rank, cloud, w, h, deg):
     return block, aux, g
 
 
+def _inverse_map(aux_np, n):
+    inv = np.full(n, -1, np.int32)
+    V = int(aux_np["num_visible"][0])
+    inv[aux_np["global_from_compact_gid"][:V]] = np.arange(V, dtype=np.int32)
+    return torch.from_numpy(inv)
+
+
 def _worker(rank, world, port, n, w, h, deg, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -72,7 +79,7 @@ def _worker(rank, world, port, n, w, h, deg, q):
                         final_index=as_i32(aux_np["final_index"]), cum_tiles_hit=as_i32(aux_np["cum_tiles_hit"]),
                         tile_bins=as_i32(aux_np["tile_bins"]), compact_gid_from_isect=as_i32(aux_np["compact_gid_from_isect"]),
                         global_from_compact_gid=as_i32(aux_np["global_from_compact_gid"]),
-                        compact_from_global_gid=torch.zeros(n, dtype=torch.int32), overflow=torch.zeros(1, dtype=torch.int32))
+                        compact_from_global_gid=_inverse_map(aux_np, n), overflow=torch.zeros(1, dtype=torch.int32))
         stats = BD.densification_stats(torch.from_numpy(g["v_xy"]), aux, (w, h))
         local_stats = stats.clone()
         BD.allreduce_densification_stats(stats)
