@@ -29,8 +29,6 @@ void set_last_hip_error(int e);
         }                                                       \
     } while (0)
 
-#define BRUSH_LAUNCH_CHECK() BRUSH_HIP_CHECK(hipGetLastError())
-
 static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -59,12 +57,6 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
         uint32_t o = __shfl_up(v, d, 64);
         if ((int)lane_id() >= d) v += o;
     }
-    return v;
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
 

@@ -5,19 +5,20 @@
 // from a GPU buffer, only the low `sorting_bits` sorted.  32-bit keys = 40 launches.
 //
 // gfx950 design: 8-bit digits (half the passes), 3 launches per pass, wave64 ranking.
-//   k_upsweep   : 256-thread block per 4096-key tile; per-wave LDS histograms -> counts[d][tile]
-//   k_scan      : one block per digit scans counts[d][*] over tiles in place, writes totals[d]
-//   k_downsweep : re-reads the tile (16 keys/lane, coalesced); each wave ranks its 1024-key
-//                 chunk with ballot match-any masks (8 x v_cmp per key, 64-bit masks), the
-//                 lowest peer lane bumps the wave's private LDS counter; 4-wave combine; the
-//                 256 digit bases come from a block scan of totals[]; scatter.
-// The element count stays on the device (*d_n): grids are sized for max_n and surplus blocks
-// exit on their first instruction.  The tile size is also chosen ON THE DEVICE from *d_n
-// (1, 2, 4, 8 or 16 keys per lane, the smallest that keeps the tile count <= 1024): a 100 k-key
-// sort then spreads over ~400 workgroups instead of 25, and an 8 M-key sort still uses 4096-key
-// tiles.  All three kernels derive the same value, so the partition is consistent.  Stability: tiles, wave chunks, rounds and lanes are all
-// ranked in index order.  Traffic per pass: 4 B/key (upsweep) + 16 B/pair (downsweep).
-// Roofline: HBM.  The pass structure sorts exactly the reference's 4*ceil(bits/4) low bits.
+//   k_upsweep   : 256-thread block per tile; per-wave LDS histograms -> counts[digit][tile]
+//   k_scan      : one block per digit scans counts[digit][*] over tiles in place, writes totals[]
+//   k_downsweep : re-reads the tile (coalesced); each wave ranks its contiguous chunk with ballot
+//                 match-any masks (8 x v_cmp per key on 64-bit masks), the lowest peer lane bumps
+//                 the wave's private LDS counter; 4-wave combine; the 256 digit bases come from a
+//                 block scan of totals[]; scatter.
+// The element count stays on the device (*d_n): grids are sized for max_n and surplus blocks exit
+// on their first instruction.  The tile size is also chosen ON THE DEVICE from *d_n (1, 2, 4, 8 or
+// 16 keys per lane, the smallest that keeps the tile count <= 1024): a 100 k-key sort then spreads
+// over ~400 workgroups instead of 25, and an 8 M-key sort still uses 4096-key tiles.  All three
+// kernels derive the same value, so the partition is consistent.
+// Stability: tiles, wave chunks, rounds and lanes are all ranked in index order.
+// Traffic per pass: 4 B/key (upsweep) + 16 B/pair (downsweep).  Roofline: HBM at large n, launch
+// latency at n ~ 100 k.  The pass structure sorts exactly the reference's 4*ceil(bits/4) low bits.
 #include "common.hpp"
 
 namespace brush {

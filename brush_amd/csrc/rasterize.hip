@@ -33,13 +33,21 @@ namespace brush {
 namespace {
 
 constexpr uint32_t kBatch = kWave;  // 64 splats per LDS batch, one per lane
-constexpr uint32_t kPix = 4;        // pixels per lane
-constexpr uint32_t kPairs = kPix / 2;
+// Pixels per lane PIX is a template parameter: 4 (one wave64 per tile) when the frame has enough
+// tiles to fill the chip, 2 (two waves per tile, 8 rows each) for small frames, where one wave
+// per tile would leave most SIMDs with a single latency-bound wave.
 
 // Pixels are processed in pairs held in float2 vectors: the arithmetic compiles to packed
 // v_pk_{mul,add,fma}_f32 (two pixels per VALU issue slot); only exp / rcp / min / compares /
 // selects stay per element.  Both raster kernels are VALU-issue bound.
 typedef float f2 __attribute__((ext_vector_type(2)));
+template <uint32_t N>
+__device__ __forceinline__ bool any_of(const bool (&b)[N]) {
+    bool r = false;
+#pragma unroll
+    for (uint32_t i = 0; i < N; i++) r = r || b[i];
+    return r;
+}
 __device__ __forceinline__ f2 splat2(float v) { return (f2){v, v}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 exp2_2(f2 v) { return (f2){__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
@@ -62,17 +70,27 @@ __device__ __forceinline__ void stage_splat(SplatLds &lds, uint32_t slot, const 
 constexpr uint32_t kTilesPerBlock = 4;  // 4 independent wave64s per 256-thread workgroup
 constexpr uint32_t kRasterThreads = kTilesPerBlock * kWave;
 
-// Every XCD (blocks b, b+8, b+16, ... share one) gets a contiguous band of tile ids; wave `wv` of
-// block `bid` takes one tile.  The grid has a multiple of 8 blocks.
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t nblocks, uint32_t wv) {
+// Every XCD (blocks b, b+8, b+16, ... share one) gets a contiguous band of work units; wave `wv`
+// of block `bid` takes one unit (a tile, or half a tile when PIX = 2).  The grid has a multiple
+// of 8 blocks.
+__device__ __forceinline__ uint32_t xcd_unit(uint32_t bid, uint32_t nblocks, uint32_t wv) {
     const uint32_t per = nblocks >> 3;
     return ((bid & 7u) * per + (bid >> 3)) * kTilesPerBlock + wv;
 }
+// Pixel block of a lane: PIX horizontally adjacent pixels.  PIX = 4: lane l -> row l/4, columns
+// 4*(l%4)..; PIX = 2: wave `sub` of the tile owns rows 8*sub..8*sub+7, lane l -> row l/8, columns 2*(l%8)..
+template <uint32_t PIX>
+struct LaneMap {
+    static constexpr uint32_t kLanesPerRow = kTileWidth / PIX;
+    static constexpr uint32_t kRowsPerWave = kWave / kLanesPerRow;
+    static constexpr uint32_t kWavesPerTile = kTileWidth / kRowsPerWave;
+    static constexpr uint32_t kPairs = PIX / 2;
+};
 // The waves of a workgroup never exchange data: LDS hand-offs are wave-local, the LDS queue of a
 // wave is in order, so a compiler-level barrier is all that is needed (no s_barrier).
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
-template <bool RASTER_U32>
+template <bool RASTER_U32, uint32_t PIX>
 __global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles,
                                                      const uint32_t *__restrict__ gid_from_isect,
                                                      const uint32_t *__restrict__ tile_bins,
@@ -80,14 +98,17 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32
                                                      void *__restrict__ out_img,
                                                      uint32_t *__restrict__ final_index) {
     __shared__ SplatLds lds_all[kTilesPerBlock];
+    using M = LaneMap<PIX>;
+    constexpr uint32_t kPix = PIX, kPairs = M::kPairs;
     const uint32_t wv = threadIdx.x / kWave;
     SplatLds &lds = lds_all[wv];
-    const uint32_t tile_id = xcd_tile(blockIdx.x, gridDim.x, wv);
+    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x, wv);
+    const uint32_t tile_id = unit / M::kWavesPerTile, sub = unit % M::kWavesPerTile;
     if (tile_id >= num_tiles) return;
     const uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t px0 = tile_x * kTileWidth + (lane & 3u) * kPix;
-    const uint32_t py = tile_y * kTileWidth + (lane >> 2);
+    const uint32_t px0 = tile_x * kTileWidth + (lane % M::kLanesPerRow) * kPix;
+    const uint32_t py = tile_y * kTileWidth + sub * M::kRowsPerWave + lane / M::kLanesPerRow;
     const float pcy = (float)py + 0.5f;  // rasterize.wgsl:32
     const float pcx0 = (float)px0 + 0.5f;
 
@@ -109,7 +130,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32
 
     const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
     for (uint32_t batch_start = r0; batch_start < r1; batch_start += kBatch) {
-        if (__ballot(live[0] || live[1] || live[2] || live[3]) == 0ull) break;
+        if (__ballot(any_of<kPix>(live)) == 0ull) break;
         const uint32_t remaining = min(kBatch, r1 - batch_start);
         wave_sync();
         if (lane < remaining) {
@@ -147,7 +168,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32
                 live[2 * p] = live[2 * p] && !sx;
                 live[2 * p + 1] = live[2 * p + 1] && !sy;
             }
-            if (__ballot(live[0] || live[1] || live[2] || live[3]) == 0ull) break;
+            if (__ballot(any_of<kPix>(live)) == 0ull) break;
         }
     }
 
@@ -219,6 +240,7 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     return v;
 }
 
+template <uint32_t PIX>
 __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
     uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles, const uint32_t *__restrict__ gid_from_isect,
     const uint32_t *__restrict__ tile_bins, const float *__restrict__ projected,
@@ -228,19 +250,22 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
     __shared__ uint32_t lds_gid_all[kTilesPerBlock][kBatch];
     __shared__ float acc_all[kTilesPerBlock][kBatch][12];  // 9 used; 48-byte rows keep b128 stores aligned
 
+    using M = LaneMap<PIX>;
+    constexpr uint32_t kPix = PIX, kPairs = M::kPairs;
     const uint32_t wv = threadIdx.x / kWave;
     SplatLds &lds = lds_all[wv];
     uint32_t *lds_gid = lds_gid_all[wv];
     float(*acc)[12] = acc_all[wv];
-    const uint32_t tile_id = xcd_tile(blockIdx.x, gridDim.x, wv);
+    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x, wv);
+    const uint32_t tile_id = unit / M::kWavesPerTile, sub = unit % M::kWavesPerTile;
     if (tile_id >= num_tiles) return;
     const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
     if (r1 <= r0) return;
 
     const uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t px0 = tile_x * kTileWidth + (lane & 3u) * kPix;
-    const uint32_t py = tile_y * kTileWidth + (lane >> 2);
+    const uint32_t px0 = tile_x * kTileWidth + (lane % M::kLanesPerRow) * kPix;
+    const uint32_t py = tile_y * kTileWidth + sub * M::kRowsPerWave + lane / M::kLanesPerRow;
     const float pcy = (float)py + 0.5f;
     const float pcx0 = (float)px0 + 0.5f;
 
@@ -275,7 +300,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
     // fail `isect_id <= final_isect` for every pixel (rasterize_backwards.wgsl:229), so the walk
     // starts at the tile's largest final index instead of the end of the list.  Exact, and in
     // saturated scenes it removes almost the whole list (the forward stopped early there too).
-    int32_t max_fin = max(max(fin[0], fin[1]), max(fin[2], fin[3]));
+    int32_t max_fin = fin[0];
+#pragma unroll
+    for (uint32_t j = 1; j < kPix; j++) max_fin = max(max_fin, fin[j]);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) max_fin = max(max_fin, __shfl_xor(max_fin, d, 64));
     const uint32_t walk_end = min(r1, (uint32_t)(max_fin + 1));
@@ -319,7 +346,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
                 m[2 * p] = isect_id <= fin[2 * p] && sigma.x >= 0.0f && alpha[p].x >= 1.0f / 255.0f;
                 m[2 * p + 1] = isect_id <= fin[2 * p + 1] && sigma.y >= 0.0f && alpha[p].y >= 1.0f / 255.0f;
             }
-            const bool any = __ballot(m[0] || m[1] || m[2] || m[3]) != 0ull;
+            const bool any = __ballot(any_of<kPix>(m)) != 0ull;
             // Pass 2: rasterize_backwards.wgsl:244-271 with selects; a pixel pair no lane of the
             // wave contributes to is skipped by a wave-uniform (scalar) branch.
             f2 gs[kGradComps];
@@ -390,20 +417,28 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
 
 }  // namespace
 
+// Work units (waves) per tile: 1 with 4 pixels per lane when the frame has at least this many
+// tiles, else 2 with 2 pixels per lane.
+constexpr uint32_t kMinTilesForOneWave = 6144;
+
 hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                             const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
                             const float *projected, int raster_u32, void *out_img, uint32_t *final_index,
                             hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
-    const dim3 grid(ceil_div(ceil_div(tiles, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
+    const bool wide = tiles >= kMinTilesForOneWave;
+    const uint32_t units = tiles * (wide ? 1u : 2u);
+    const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
+#define BRUSH_RASTER(U32, PIX)                                                                              \
+    hipLaunchKernelGGL((k_rasterize<U32, PIX>), grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, \
+                       tile_bins, projected, out_img, final_index)
     if (raster_u32) {
-        hipLaunchKernelGGL(k_rasterize<true>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins,
-                           projected, out_img, final_index);
+        if (wide) BRUSH_RASTER(true, 4); else BRUSH_RASTER(true, 2);
     } else {
-        hipLaunchKernelGGL(k_rasterize<false>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins,
-                           projected, out_img, final_index);
+        if (wide) BRUSH_RASTER(false, 4); else BRUSH_RASTER(false, 2);
     }
+#undef BRUSH_RASTER
     return hipGetLastError();
 }
 
@@ -414,9 +449,16 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
                                      hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
-    const dim3 grid(ceil_div(ceil_div(tiles, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
-    hipLaunchKernelGGL(k_rasterize_backward, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins,
-                       projected, final_index, out_img, v_out, v_compact);
+    const bool wide = tiles >= kMinTilesForOneWave;
+    const uint32_t units = tiles * (wide ? 1u : 2u);
+    const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
+    if (wide) {
+        hipLaunchKernelGGL(k_rasterize_backward<4>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
+                           tile_bins, projected, final_index, out_img, v_out, v_compact);
+    } else {
+        hipLaunchKernelGGL(k_rasterize_backward<2>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
+                           tile_bins, projected, final_index, out_img, v_out, v_compact);
+    }
     return hipGetLastError();
 }
 
