@@ -14,6 +14,7 @@ struct WalkWs {
     uint32_t *chunk_count;  // [capacity]
     uint32_t *chunk_mask;   // [capacity * 8] (four 64-bit hit masks per item)
     uint32_t *slot_of;      // [N]
+    uint32_t *inline_mask;  // [N * 2] (64-bit hit mask per inline splat)
     uint32_t capacity;
 };
 size_t cull_block_count(uint32_t n);

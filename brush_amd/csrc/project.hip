@@ -31,13 +31,18 @@ namespace {
 constexpr uint32_t kThreads = 256;
 // Tile walks.  A splat's bbox holds 1 .. tiles_x*tiles_y candidate tiles and the exact
 // can_be_visible test costs ~300 VALU instructions, so the walk is split by size:
-//   * bboxes of <= kSmallArea tiles are walked by their own lane, inline;
+//   * bboxes of <= kSmallArea (64) tiles are walked inside project_visible, but not lane by lane:
+//     the candidate tiles of the wave's 64 splats are flattened into one list (wave prefix sum of
+//     the bbox areas), every lane tests one candidate per step after finding its owner splat with
+//     a 6-step shuffle binary search, and each owner harvests its hit bits from the step's ballot
+//     (count + 64-bit hit mask).  All lanes do useful tests regardless of how uneven the areas are;
 //   * larger ones are cut into chunks of kChunkTiles tiles and queued as (splat, chunk) work items
-//     (one atomicAdd reserves a splat's consecutive slots).  A second launch consumes the queue
+//     (one atomicAdd per wave reserves consecutive slots).  A second launch consumes the queue
 //     one wave64 per item, 64 tiles per step, so a whole-screen splat is spread over dozens of
-//     waves and no lane ever walks more than kSmallArea tiles.
+//     waves.
 // If the queue is full the lane falls back to walking its bbox inline (slow, still correct).
-constexpr uint32_t kSmallArea = 8;
+// The hit masks are kept so that the emission pass never repeats the exact test.
+constexpr uint32_t kSmallArea = 64;
 constexpr uint32_t kChunkTiles = 256;
 
 struct WalkQueue {
@@ -45,27 +50,67 @@ struct WalkQueue {
     uint2 *items;           // [capacity] (compact gid, chunk index)
     uint32_t *chunk_count;  // [capacity] tiles hit inside the chunk (written by the count pass)
     uint64_t *chunk_mask;   // [capacity][4] hit bitmask of the chunk's 256 tiles (count pass -> emit pass)
-    uint32_t *slot_of;      // [N] queued splat: first item slot (< 2^31); inline splat:
-                            //     kInlineFlag | hit mask of its <= 8 bbox tiles, or kInlineRetest
+    uint32_t *slot_of;      // [N] queued splat: first item slot (< 2^31); inline splat: kInlineFlag
+                            //     (hit mask in inline_mask) or kInlineRetest
+    uint64_t *inline_mask;  // [N] hit mask of an inline splat's <= 64 bbox tiles (row-major)
     uint32_t capacity;
 };
 // The count pass records WHICH tiles passed, so the emit pass never repeats the exact test.
 constexpr uint32_t kInlineFlag = 0x80000000u;
 constexpr uint32_t kInlineRetest = 0xFFFFFFFFu;  // walked inline because the queue was full
 
-// Returns the hit mask of a small bbox (bit i = i-th tile in row-major order); for larger bboxes
-// (queue-full fallback) only the count is meaningful.
-__device__ __forceinline__ uint32_t walk_inline_count(const uint32_t bb[4], const TileTest &tt, const float xy[2],
-                                                      uint32_t &mask) {
-    uint32_t cnt = 0, i = 0;
-    mask = 0;
+// Serial walk of one bbox by its own lane (queue-full fallback only).
+__device__ __forceinline__ uint32_t walk_inline_count(const uint32_t bb[4], const TileTest &tt, const float xy[2]) {
+    uint32_t cnt = 0;
     for (uint32_t ty = bb[1]; ty < bb[3]; ty++)
-        for (uint32_t tx = bb[0]; tx < bb[2]; tx++, i++)
-            if (can_be_visible(tt, tx, ty, xy)) {
-                cnt++;
-                if (i < 31) mask |= 1u << i;
-            }
+        for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
+            if (can_be_visible(tt, tx, ty, xy)) cnt++;
     return cnt;
+}
+
+// Wave-flattened walk of the wave's small bboxes.  `area` = this lane's bbox tile count (0 if the
+// lane has no small bbox).  Must be called by all 64 lanes.  Returns this lane's hit count and
+// its row-major hit mask.
+__device__ __forceinline__ void walk_flat(uint32_t area, const uint32_t bb[4], const TileTest &tt, const float xy[2],
+                                          uint32_t &cnt, uint64_t &mask) {
+    const uint32_t lane = lane_id();
+    const uint32_t bw = bb[2] - bb[0];
+    cnt = 0;
+    mask = 0;
+    const uint32_t incl = wave_inclusive_scan(area);
+    const uint32_t excl = incl - area;
+    const uint32_t total = __shfl(incl, 63, 64);
+    for (uint32_t base = 0; base < total; base += kWave) {  // wave-uniform
+        const uint32_t j = base + lane;
+        // owner = number of lanes whose inclusive prefix is <= j (prefixes are non-decreasing)
+        uint32_t own = 0;
+#pragma unroll
+        for (uint32_t step = 32; step > 0; step >>= 1)
+            if (__shfl(incl, own + step - 1, 64) <= j) own += step;
+        own = min(own, kWave - 1);
+        TileTest ot;
+        ot.q[0] = __shfl(tt.q[0], own, 64);
+        ot.q[1] = __shfl(tt.q[1], own, 64);
+        ot.q[2] = __shfl(tt.q[2], own, 64);
+        ot.any = __shfl((int)tt.any, own, 64) != 0;
+        const float oxy[2] = {__shfl(xy[0], own, 64), __shfl(xy[1], own, 64)};
+        const uint32_t ob0 = __shfl(bb[0], own, 64), ob1 = __shfl(bb[1], own, 64);
+        const uint32_t obw = __shfl(bw, own, 64), oexcl = __shfl(excl, own, 64);
+        bool hit = false;
+        if (j < total) {
+            const uint32_t li = j - oexcl;
+            hit = can_be_visible(ot, ob0 + li % obw, ob1 + li / obw, oxy);
+        }
+        const uint64_t bal = __ballot(hit);
+        // harvest: this lane's candidates occupy [excl, incl) of the flattened list
+        const uint32_t lo = max(excl, base), hi = min(incl, base + kWave);
+        if (lo < hi) {
+            const uint32_t len = hi - lo;
+            const uint64_t seg = (bal >> (lo - base)) & (len == 64 ? ~0ull : ((1ull << len) - 1ull));
+            cnt += __popcll(seg);
+            mask |= seg << (lo - excl);
+        }
+    }
 }
 
 __device__ __forceinline__ void walk_inline_emit(const uint32_t bb[4], const TileTest &tt, const float xy[2],
@@ -315,10 +360,18 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
                 for (uint32_t k = first; k < q.capacity; k++) q.items[k] = make_uint2(kInvalid, 0u);
             }
         }
-        if (active && slot == kInvalid) {
-            uint32_t mask;
-            area = walk_inline_count(bb, tt, xy, mask);
-            slot = bbox_tiles <= kSmallArea ? (kInlineFlag | mask) : kInlineRetest;
+        // small bboxes: flattened across the wave
+        const bool small = active && bbox_tiles <= kSmallArea;
+        uint32_t flat_cnt;
+        uint64_t flat_mask;
+        walk_flat(small ? bbox_tiles : 0u, bb, tt, xy, flat_cnt, flat_mask);
+        if (small) {
+            area = flat_cnt;
+            slot = kInlineFlag;
+            q.inline_mask[c] = flat_mask;
+        } else if (active && slot == kInvalid) {  // queue full
+            area = walk_inline_count(bb, tt, xy);
+            slot = kInlineRetest;
         }
         if (active) q.slot_of[c] = slot;
         if (active) {
@@ -390,9 +443,9 @@ __global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, cons
         } else {
             // replay the hit mask recorded by project_visible (row-major over the bbox)
             const uint32_t bw = bb[2] - bb[0];
-            uint32_t mask = code & ~kInlineFlag;
+            uint64_t mask = q.inline_mask[c];
             while (mask) {
-                const uint32_t i = __ffs((int)mask) - 1;
+                const uint32_t i = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 if (isect < cap) {
                     tile_ids[isect] = (bb[0] + i % bw) + (bb[1] + i / bw) * vp.tile_bounds[0];
@@ -475,6 +528,7 @@ WalkQueue make_queue(const WalkWs &w) {
     q.chunk_count = w.chunk_count;
     q.chunk_mask = reinterpret_cast<uint64_t *>(w.chunk_mask);
     q.slot_of = w.slot_of;
+    q.inline_mask = reinterpret_cast<uint64_t *>(w.inline_mask);
     q.capacity = w.capacity;
     return q;
 }

@@ -82,6 +82,7 @@ FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap) {
     f.walk.chunk_count = c.take<uint32_t>(nn);
     f.walk.chunk_mask = c.take<uint32_t>(nn * 8);
     f.walk.slot_of = c.take<uint32_t>(nn);
+    f.walk.inline_mask = c.take<uint32_t>(nn * 2);
     f.bytes = c.bytes();
     return f;
 }
