@@ -29,6 +29,8 @@ namespace brush {
 namespace {
 
 constexpr uint32_t kThreads = 256;
+constexpr uint32_t kCullPerThread = 4;                     // splats per lane in the cull / compact kernels
+constexpr uint32_t kCullBlock = kThreads * kCullPerThread;  // splats per cull workgroup
 // Tile walks.  A splat's bbox holds 1 .. tiles_x*tiles_y candidate tiles and the exact
 // can_be_visible test costs ~300 VALU instructions, so the walk is split by size:
 //   * bboxes of <= kSmallArea (64) tiles are walked inside project_visible, but not lane by lane:
@@ -165,46 +167,70 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                                            uint32_t *__restrict__ tile_bins, uint32_t num_bin_words,
                                                            uint32_t *__restrict__ walk_counter) {
     __shared__ uint32_t wave_cnt[kThreads / kWave];
-    const uint32_t g = blockIdx.x * kThreads + threadIdx.x;
-    if (g < kUniformWords) uniforms_buffer[g] = reinterpret_cast<const uint32_t *>(&u)[g];
-    if (g == 0) {
+    const uint32_t gt = blockIdx.x * kThreads + threadIdx.x;
+    if (gt < kUniformWords) uniforms_buffer[gt] = reinterpret_cast<const uint32_t *>(&u)[gt];
+    if (gt == 0) {
         *num_intersections = 0;
         *overflow = 0;
         *walk_counter = 0;
     }
-    for (uint32_t i = g; i < num_bin_words; i += gridDim.x * kThreads) tile_bins[i] = 0;
-    bool visible = false;
-    float depth = 0.0f;
-    if (g < vp.total_splats) {
-        const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
-        float p_view[3];
-        to_view(vp, mean, p_view);
-        if (p_view[2] > 0.01f) {  // :32
-            const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
-                                    det_expf(log_scales[(size_t)g * 3 + 2])};
+    for (uint32_t i = gt; i < num_bin_words; i += gridDim.x * kThreads) tile_bins[i] = 0;  // render.rs:241-244
+
+    // kCullPerThread independent splats per lane (round r covers 256 consecutive splats).
+    uint32_t block_visible = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < kCullPerThread; r++) {
+        const uint32_t g = blockIdx.x * kCullBlock + r * kThreads + threadIdx.x;
+        bool visible = false;
+        float depth = 0.0f;
+        if (g < vp.total_splats) {
+            // All 40 bytes of the splat are requested up front (one memory phase per wave instead of
+            // three dependent ones); the culls below only decide how much arithmetic follows.
+            const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
+            const float lsv[3] = {log_scales[(size_t)g * 3], log_scales[(size_t)g * 3 + 1], log_scales[(size_t)g * 3 + 2]};
             const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
-            const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-            float cov2d[3];
-            calc_cov2d(vp, p_view, scale, quat, cov2d);
-            const float det = cov2d[0] * cov2d[2] - cov2d[1] * cov2d[1];
-            if (!(det == 0.0f)) {  // :43
-                float conic[3], xy[2];
-                cov_to_conic(cov2d, conic);
-                project_pix(vp, p_view, xy);
-                const uint32_t radius = radius_from_conic(conic);
-                uint32_t bb[4];
-                get_tile_bbox(xy, radius, vp.tile_bounds, bb);
-                if ((bb[2] - bb[0]) != 0u && (bb[3] - bb[1]) != 0u) {  // :60
-                    visible = true;
-                    depth = p_view[2];
+            float p_view[3];
+            to_view(vp, mean, p_view);
+            bool maybe = p_view[2] > 0.01f;  // :32
+            if (maybe) {
+                // Conservative early reject (never changes a decision): radius <= 3*sqrt(lambda_max + quirk
+                // slack) + 1 with lambda_max(cov2d) <= trace <= s_max^2 * cull_k / z^2 + 0.6; if even that
+                // radius leaves the tile bbox empty, the exact test below (:54-62) would reject as well.
+                const float smax = det_expf(fmaxf(lsv[0], fmaxf(lsv[1], lsv[2]))) * 1.001f;
+                const float rz = 1.0f / p_view[2];
+                const float lam = smax * smax * vp.cull_k * rz * rz + 1.0f;
+                const float rb = 3.0f * sqrtf(lam) + 2.0f;
+                const float cxp = p_view[0] * rz * vp.focal[0] + vp.pixel_center[0];
+                const float cyp = p_view[1] * rz * vp.focal[1] + vp.pixel_center[1];
+                const float wpx = (float)(vp.tile_bounds[0] * kTileWidth), hpx = (float)(vp.tile_bounds[1] * kTileWidth);
+                if (cxp + rb < -1.0f || cxp - rb > wpx + 1.0f || cyp + rb < -1.0f || cyp - rb > hpx + 1.0f) maybe = false;
+            }
+
+            if (maybe) {
+                const float scale[3] = {det_expf(lsv[0]), det_expf(lsv[1]), det_expf(lsv[2])};
+                const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+                float cov2d[3];
+                calc_cov2d(vp, p_view, scale, quat, cov2d);
+                const float det = cov2d[0] * cov2d[2] - cov2d[1] * cov2d[1];
+                if (!(det == 0.0f)) {  // :43
+                    float conic[3], xy[2];
+                    cov_to_conic(cov2d, conic);
+                    project_pix(vp, p_view, xy);
+                    const uint32_t radius = radius_from_conic(conic);
+                    uint32_t bb[4];
+                    get_tile_bbox(xy, radius, vp.tile_bounds, bb);
+                    if ((bb[2] - bb[0]) != 0u && (bb[3] - bb[1]) != 0u) {  // :60
+                        visible = true;
+                        depth = p_view[2];
+                    }
                 }
             }
+            key_all[g] = visible ? __float_as_uint(depth) : kInvalid;
+            compact_from_global[g] = kInvalid;
         }
-        key_all[g] = visible ? __float_as_uint(depth) : kInvalid;
-        compact_from_global[g] = kInvalid;
+        block_visible += __popcll(__ballot(visible));
     }
-    const uint64_t b = __ballot(visible);
-    if (lane_id() == 0) wave_cnt[threadIdx.x / kWave] = __popcll(b);
+    if (lane_id() == 0) wave_cnt[threadIdx.x / kWave] = block_visible;
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
@@ -236,23 +262,35 @@ __global__ __launch_bounds__(1024) void k_cull_scan(uint32_t *__restrict__ block
     }
 }
 
-// Order-preserving compaction of (depth key, global id).
+// Order-preserving compaction of (depth key, global id); same 1024-splat partition as the cull.
 __global__ __launch_bounds__(kThreads) void k_compact(uint32_t n, const uint32_t *__restrict__ key_all,
                                                       const uint32_t *__restrict__ block_offsets,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ gids) {
-    __shared__ uint32_t wave_cnt[kThreads / kWave];
-    const uint32_t g = blockIdx.x * kThreads + threadIdx.x;
-    const uint32_t key = g < n ? key_all[g] : kInvalid;
-    const bool visible = key != kInvalid;
-    const uint64_t b = __ballot(visible);
+    __shared__ uint32_t wave_cnt[kCullPerThread][kThreads / kWave];
     const uint32_t wid = threadIdx.x / kWave;
-    if (lane_id() == 0) wave_cnt[wid] = __popcll(b);
+    uint32_t key[kCullPerThread];
+    uint64_t bal[kCullPerThread];
+#pragma unroll
+    for (uint32_t r = 0; r < kCullPerThread; r++) {
+        const uint32_t g = blockIdx.x * kCullBlock + r * kThreads + threadIdx.x;
+        key[r] = g < n ? key_all[g] : kInvalid;
+        bal[r] = __ballot(key[r] != kInvalid);
+        if (lane_id() == 0) wave_cnt[r][wid] = __popcll(bal[r]);
+    }
     __syncthreads();
-    if (visible) {
-        uint32_t off = block_offsets[blockIdx.x] + __popcll(b & lanemask_lt());
-        for (uint32_t w = 0; w < wid; w++) off += wave_cnt[w];
-        keys[off] = key;
-        gids[off] = g;
+    uint32_t off = block_offsets[blockIdx.x];
+#pragma unroll
+    for (uint32_t r = 0; r < kCullPerThread; r++) {
+        uint32_t mine = off + __popcll(bal[r] & lanemask_lt());
+        for (uint32_t w = 0; w < kThreads / kWave; w++) {
+            const uint32_t c = wave_cnt[r][w];
+            if (w < wid) mine += c;
+            off += c;
+        }
+        if (key[r] != kInvalid) {
+            keys[mine] = key[r];
+            gids[mine] = blockIdx.x * kCullBlock + r * kThreads + threadIdx.x;
+        }
     }
 }
 
@@ -535,7 +573,7 @@ WalkQueue make_queue(const WalkWs &w) {
 
 }  // namespace
 
-size_t cull_block_count(uint32_t n) { return ceil_div(n ? n : 1, kThreads); }
+size_t cull_block_count(uint32_t n) { return ceil_div(n ? n : 1, kCullBlock); }
 
 hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, const BrushAux &aux,
                                uint32_t num_tiles, const float *means, const float *log_scales,

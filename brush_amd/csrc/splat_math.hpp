@@ -52,6 +52,7 @@ struct ViewParams {
     uint32_t tile_bounds[2];
     uint32_t sh_degree;
     uint32_t total_splats;
+    float cull_k;  // upper bound of (z * |J W|_F)^2, see make_view_params
 };
 
 inline ViewParams make_view_params(const BrushUniforms &u, uint32_t n) {
@@ -65,6 +66,21 @@ inline ViewParams make_view_params(const BrushUniforms &u, uint32_t n) {
     }
     v.sh_degree = u.sh_degree;
     v.total_splats = n;
+    // Conservative cull constant.  cov = (J W) V (J W)^T with |V|_2 = s_max^2, so
+    // lambda_max(cov) <= s_max^2 |J|_F^2 |W|_F^2, and with t clamped to z*lims (helpers.wgsl:127-134)
+    // |J|_F^2 <= (fx^2 (1 + lx^2) + fy^2 (1 + ly^2)) / z^2.  1 % head-room for rounding.
+    double wf2 = 0.0;
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) wf2 += (double)u.viewmat[c * 4 + r] * u.viewmat[c * 4 + r];
+    double k = 0.0;
+    for (int i = 0; i < 2; i++) {
+        const double f = u.focal[i], img = u.img_size[i], pc = u.pixel_center[i];
+        const double tan_fov = 0.5 * img / f;
+        const double lp = (img - pc) / f + 0.3 * tan_fov, ln = pc / f + 0.3 * tan_fov;
+        const double l = lp > ln ? lp : ln;
+        k += f * f * (1.0 + l * l);
+    }
+    v.cull_k = (float)(k * wf2 * 1.01);
     return v;
 }
 
