@@ -36,6 +36,22 @@ class Splats(torch.nn.Module):
 
         return cls(dev(t["means"]), dev(t["coeffs"]), dev(t["quats"]), dev(t["opacities"]), dev(t["scales"]))
 
+    @classmethod
+    def from_ply(cls, path_or_bytes, device):
+        """crates/brush-dataset/src/splat_import.rs:183-312 (without the streaming updates)."""
+        from .ply import load_splat_from_ply
+
+        d = load_splat_from_ply(path_or_bytes)
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device)
+        return cls(t(d["means"]), t(d["sh_coeffs"]), t(d["rotation"]), t(d["raw_opacity"]), t(d["log_scales"]))
+
+    def to_ply(self) -> bytes:
+        """crates/brush-dataset/src/splat_export.rs:67-105"""
+        from .ply import splat_to_ply
+
+        c = lambda p: p.detach().cpu().numpy()
+        return splat_to_ply(c(self.means), c(self.log_scales), c(self.rotation), c(self.raw_opacity), c(self.sh_coeffs))
+
     def num_splats(self) -> int:
         return self.means.shape[0]
 
