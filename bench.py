@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=20, help="extra steps with stage events (untimed)")
     ap.add_argument("--train-steps", type=int, default=20,
                     help="extra (untimed for `value`) steps of the full training iteration: loss + Adam groups")
+    ap.add_argument("--dense-allreduce", action="store_true",
+                    help="N>1: all-reduce the dense 52+12C B/splat block instead of all-gathering the compact "
+                         "60 B/visible-splat records (brush_amd/dist.py)")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every launch from the host instead of replaying one captured hipGraph per step")
     return ap.parse_args()
@@ -93,12 +96,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # Rehearsal hooks (not used by the driver): BRUSH_BENCH_DEVICE pins every rank to one device and
+    # BRUSH_DIST_BACKEND=gloo replaces RCCL, so the N>1 code path can be exercised on a 1-GPU box.
+    if "BRUSH_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["BRUSH_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        backend = os.environ.get("BRUSH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
 
     import brush_amd
@@ -144,8 +155,11 @@ def main():
             aux = graph_aux
         else:
             aux = fwd_bwd()
-        if world > 1:
-            BD.allreduce_param_grads(block, n, C)  # one RCCL all-reduce of the dense gradient prefix
+        if world > 1:  # sum of the per-view gradients on every rank (RCCL over xGMI)
+            if args.dense_allreduce:
+                BD.allreduce_param_grads(block, n, C)
+            else:
+                BD.allreduce_param_grads_compact(block, aux, p["means"], n, C)
         return aux
 
     def barrier():
@@ -270,6 +284,9 @@ def main():
             "config": {"workload": f"S1: {n} splats @{w}x{h}, SH degree {deg}, seed 4, mean_mult {args.mean_mult}, "
                                    f"fwd+bwd per view", "views_per_step": n_gpus,
                        "parallelism": f"view-sharded dp{n_gpus}" if n_gpus > 1 else "single GPU",
+                       "gradient_exchange": None if n_gpus == 1 else (
+                           "dense all-reduce" if args.dense_allreduce else
+                           "all-gather of compact per-view records + local expansion (same dense sum)"),
                        "launch": "eager" if graph is None else "hipGraph replay of one fwd+bwd",
                        "num_visible": V, "num_intersections": I, "max_intersects": aux.max_intersects,
                        "overflow": overflow},

@@ -42,6 +42,170 @@ def allreduce_param_grads(block: torch.Tensor, n: int, ncoef: int, average: bool
     return block
 
 
+# --------------------------------------------------------------------------------------------
+# Compact gradient exchange
+#
+# One view touches ~10 % of the splats and its SH gradient row is rank one,
+# v_sh[g] = Y(dir_view(g)) (x) v_rgb[g] (gather_grads.wgsl:186-222), so the view's whole parameter
+# gradient is described by 15 numbers per VISIBLE splat:
+#     gid | v_means(3) | v_scales(3) | v_quats(4) | v_opac | v_sh[g,0,:](3)      (60 bytes)
+# instead of 52+12C bytes per splat (244 at SH degree 3).  Every rank all-gathers the records of
+# all views (RCCL all_gather, padded to the largest view) and expands + sums them locally into the
+# dense block; Y is recomputed from the replicated means and each view's camera term.  The result
+# on every rank is the same dense sum an all-reduce would give (up to f32 summation order and one
+# extra rounding in v_rgb = v_sh0 / Y0); the bytes on xGMI drop from ~2*(W-1)/W*247 MB to
+# (W-1)*6 MB per rank at N = 1 M, SH degree 3, which is what makes 2..8 GPUs scale when a view
+# takes only ~0.5 ms to render.
+# --------------------------------------------------------------------------------------------
+_REC = 16  # floats per record (15 used, 64-byte rows)
+_SH_C0 = 0.2820947917738781
+
+
+def sh_basis_torch(degree: int, d: torch.Tensor) -> torch.Tensor:
+    """Sloan basis of project_visible.wgsl:51-147 / gather_grads.wgsl:17-112 for unit dirs [M,3] -> [M,C]."""
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    Y = [torch.full_like(x, _SH_C0)]
+    if degree >= 1:
+        a = 0.48860251190292
+        Y += [-a * y, a * z, -a * x]
+    if degree >= 2:
+        z2 = z * z
+        f0b = -1.092548430592079 * z
+        f1a = 0.5462742152960395
+        c1 = x * x - y * y
+        s1 = 2.0 * x * y
+        p6 = 0.9461746957575601 * z2 - 0.3153915652525201
+        Y += [f1a * s1, f0b * y, p6, f0b * x, f1a * c1]
+    if degree >= 3:
+        f0c = -2.285228997322329 * z2 + 0.4570457994644658
+        f1b = 1.445305721320277 * z
+        f2a = -0.5900435899266435
+        c2 = x * c1 - y * s1
+        s2 = x * s1 + y * c1
+        p12 = z * (1.865881662950577 * z2 - 1.119528997770346)
+        Y += [f2a * s2, f1b * s1, f0c * y, p12, f0c * x, f1b * c1, f2a * c2]
+    if degree >= 4:
+        f0d = z * (-4.683325804901025 * z2 + 2.007139630671868)
+        f1c = 3.31161143515146 * z2 - 0.47308734787878
+        f2b = -1.770130769779931 * z
+        f3a = 0.6258357354491763
+        c3 = x * c2 - y * s2
+        s3 = x * s2 + y * c2
+        Y += [f3a * s3, f2b * s2, f1c * s1, f0d * y, 1.984313483298443 * z * p12 - 1.006230589874905 * p6, f0d * x,
+              f1c * c1, f2b * c2, f3a * c3]
+    return torch.stack(Y, dim=1)
+
+
+def pack_view_records(block: torch.Tensor, aux: RenderAux, n: int, ncoef: int, rows: int) -> torch.Tensor:
+    """[rows, 16] f32 records of this view's visible splats (rows >= num_visible; tail rows have
+    column 15 == 0 and are ignored).  Column 0 carries the global id as int32 bits."""
+    layout, _ = grad_block_layout(n, ncoef)
+    dev = block.device
+    idx = torch.arange(rows, device=dev)
+    valid = idx < aux.num_visible.to(idx.dtype)
+    gid = torch.where(valid, aux.global_from_compact_gid[:n].long()[idx.clamp(max=max(n - 1, 0))], torch.zeros_like(idx))
+
+    def seg(name, width):
+        off, sz = layout[name]
+        return block[off:off + sz].view(n, width)
+
+    rec = torch.zeros((rows, _REC), dtype=torch.float32, device=dev)
+    rec[:, 0] = gid.to(torch.int32).view(torch.float32)
+    rec[:, 1:4] = seg("v_means", 3)[gid]
+    rec[:, 4:7] = seg("v_scales", 3)[gid]
+    rec[:, 7:11] = seg("v_quats", 4)[gid]
+    rec[:, 11] = seg("v_opac", 1)[gid, 0]
+    rec[:, 12:15] = seg("v_sh", ncoef * 3)[gid, 0:3]
+    rec[:, 15] = valid.to(torch.float32)
+    return rec
+
+
+def expand_view_records(recs: torch.Tensor, campos: torch.Tensor, means: torch.Tensor, block: torch.Tensor,
+                        n: int, ncoef: int, own_view: Optional[int] = None) -> torch.Tensor:
+    """Sums the records of the views ([W, rows, 16], camera terms [W, 3] = viewmat[3].xyz of each
+    view) into the parameter prefix of `block` with the HIP kernel brush_expand_view_records.
+    own_view=None: the prefix is overwritten by the sum of all W views; own_view=r: `block` already
+    holds view r's dense gradients and the other views are added on top.  Device tensors only (no
+    CPU path); the torch restatement below is the test reference."""
+    import ctypes as C
+
+    from . import _lib
+
+    assert block.is_cuda and recs.is_cuda and means.is_cuda, "brush_amd has no CPU path: tensors must live on the GPU"
+    layout, _ = grad_block_layout(n, ncoef)
+    W, rows, _ = recs.shape
+    recs, campos, means = recs.contiguous(), campos.contiguous(), means.contiguous()
+
+    def ptr(name):
+        off, _sz = layout[name]
+        return block.data_ptr() + off * 4
+
+    degree = int(round(ncoef ** 0.5)) - 1
+    with torch.cuda.device(block.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        skip = 0xFFFFFFFF if own_view is None else int(own_view)
+        _lib.check(_lib.lib().brush_expand_view_records(recs.data_ptr(), W * rows, rows, campos.data_ptr(),
+                                                        means.data_ptr(), n, degree, skip, ptr("v_means"), ptr("v_scales"),
+                                                        ptr("v_quats"), ptr("v_opac"), ptr("v_sh"), stream),
+                   "brush_expand_view_records")
+    return block
+
+
+def expand_view_records_torch(recs: torch.Tensor, campos: torch.Tensor, means: torch.Tensor, block: torch.Tensor,
+                              n: int, ncoef: int, own_view: Optional[int] = None) -> torch.Tensor:
+    """Plain-torch restatement of brush_expand_view_records (reference for the tests; also what the
+    world_size-2 gloo test on CPU uses)."""
+    layout, _ = grad_block_layout(n, ncoef)
+    W, rows, _ = recs.shape
+    flat = recs.reshape(W * rows, _REC)
+    keep = flat[:, 15] > 0.5
+    if own_view is not None:
+        keep = keep & (torch.arange(W * rows, device=flat.device) // rows != own_view)
+    gid = flat[:, 0].contiguous().view(torch.int32).long()
+    gid = torch.where(keep, gid, torch.zeros_like(gid))
+    w = keep.to(torch.float32)[:, None]
+    cam = campos.repeat_interleave(rows, dim=0)
+    d = means[gid] - cam
+    d = d / torch.sqrt(torch.sum(d * d, dim=1, keepdim=True))
+    degree = int(round(ncoef ** 0.5)) - 1
+    Y = sh_basis_torch(degree, d)                        # [M, C]
+    rgb = flat[:, 12:15] * (w / _SH_C0)                  # v_rgb = v_sh0 / Y0 (0 for padding rows)
+    Y = torch.where(keep[:, None], Y, torch.zeros_like(Y))  # padding rows may have NaN dirs
+
+    if own_view is None:
+        block[:param_grad_floats(n, ncoef)].zero_()
+
+    def seg(name, width):
+        off, sz = layout[name]
+        return block[off:off + sz].view(n, width)
+
+    seg("v_means", 3).index_add_(0, gid, flat[:, 1:4] * w)
+    seg("v_scales", 3).index_add_(0, gid, flat[:, 4:7] * w)
+    seg("v_quats", 4).index_add_(0, gid, flat[:, 7:11] * w)
+    seg("v_opac", 1).index_add_(0, gid, flat[:, 11:12] * w)
+    seg("v_sh", ncoef * 3).index_add_(0, gid, (Y[:, :, None] * rgb[:, None, :]).reshape(-1, ncoef * 3))
+    return block
+
+
+def allreduce_param_grads_compact(block: torch.Tensor, aux: RenderAux, means: torch.Tensor, n: int, ncoef: int,
+                                  group: Optional[dist.ProcessGroup] = None, expand=None) -> torch.Tensor:
+    """Same result as allreduce_param_grads (sum over views, every rank) through an all-gather of
+    compact per-view records.  One small all-reduce(MAX) + host read sizes the padded exchange."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return block
+    world = dist.get_world_size(group)
+    vmax = aux.num_visible.to(torch.int64).clone()
+    dist.all_reduce(vmax, op=dist.ReduceOp.MAX, group=group)
+    rows = max(256, -(-int(vmax.item()) // 256) * 256)
+    rec = pack_view_records(block, aux, n, ncoef, rows)
+    words = aux.uniforms_buffer[12:15].contiguous().view(torch.float32)  # viewmat[3].xyz (SURVEY §2b-1)
+    recs = torch.empty((world, rows, _REC), dtype=torch.float32, device=block.device)
+    cams = torch.empty((world, 3), dtype=torch.float32, device=block.device)
+    dist.all_gather_into_tensor(recs.view(-1), rec.view(-1), group=group)
+    dist.all_gather_into_tensor(cams.view(-1), words.clone(), group=group)
+    return (expand or expand_view_records)(recs, cams, means, block, n, ncoef, dist.get_rank(group))
+
+
 def densification_stats(v_xy: torch.Tensor, aux: RenderAux, img_size) -> torch.Tensor:
     """Per-view statistics of train.rs:284-316 packed as [2, N] f32:
     row 0 = ||v_xy * (w/2, h/2)||, row 1 = 1 for splats visible in this view else 0."""

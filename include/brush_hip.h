@@ -138,6 +138,21 @@ int brush_render_backward(const BrushUniforms *h_uniforms, const BrushAux *h_aux
                           float *v_quats, float *v_sh, float *v_opac, void *workspace,
                           size_t workspace_bytes, brush_stream_t stream);
 
+/* ---- multi-GPU gradient exchange (build extension; the reference is single-device) ------- */
+/* Sums the compact gradient records of W views into the dense parameter-gradient arrays.
+ * skip_view = 0xFFFFFFFF: the arrays are zero-filled first and all W views are added;
+ * skip_view = r: the arrays are expected to hold view r's dense gradients already (the caller's
+ * own backward output) and the other W-1 views are added on top.  records: [num_records][16] f32 =
+ *   [gid as u32 bits | v_means(3) | v_scales(3) | v_quats(4) | v_opac | v_sh[gid,0,:](3) | valid],
+ * view of record r = r / rows_per_view; campos: [W][3] = viewmat[3].xyz of each view (the term the
+ * reference uses as camera position, project_visible.wgsl:232-233); means: [N,3].  The SH rows are
+ * rebuilt as Y(normalize(mean - campos)) (x) v_sh0 / Y0 (gather_grads.wgsl:186-222).  See
+ * brush_amd/dist.py for the all-gather that produces `records`. */
+int brush_expand_view_records(const float *records, uint32_t num_records, uint32_t rows_per_view,
+                              const float *campos, const float *means, uint32_t n, uint32_t sh_degree,
+                              uint32_t skip_view, float *v_means, float *v_scales, float *v_quats,
+                              float *v_opac, float *v_sh, brush_stream_t stream);
+
 /* ---- opt-in stage timing ---------------------------------------------------------------- */
 /* Counterpart of the reference's tracing spans + sync-span layer (render.rs:69-267,474-577;
  * crates/sync-span/src/lib.rs:12-49): when a profiler is attached to the calling host thread,

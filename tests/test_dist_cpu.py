@@ -80,10 +80,18 @@ def _worker(rank, world, port, n, w, h, deg, q):
                         tile_bins=as_i32(aux_np["tile_bins"]), compact_gid_from_isect=as_i32(aux_np["compact_gid_from_isect"]),
                         global_from_compact_gid=as_i32(aux_np["global_from_compact_gid"]),
                         compact_from_global_gid=_inverse_map(aux_np, n), overflow=torch.zeros(1, dtype=torch.int32))
+        # compact exchange: all-gather of 60-byte records of the visible splats + local expansion
+        ub = torch.zeros(28, dtype=torch.int32)
+        ub[:16] = torch.from_numpy(_view_uniforms(rank, w, h, deg)["viewmat"].view(np.int32).copy())
+        aux.uniforms_buffer = ub
+        block_c = torch.from_numpy(block_np.copy())
+        BD.allreduce_param_grads_compact(block_c, aux, torch.from_numpy(cloud["means"]), n, ncoef,
+                                         expand=BD.expand_view_records_torch)
         stats = BD.densification_stats(torch.from_numpy(g["v_xy"]), aux, (w, h))
         local_stats = stats.clone()
         BD.allreduce_densification_stats(stats)
-        q.put((rank, block.numpy(), block_np, local_stats.numpy(), stats.numpy(), int(aux_np["num_visible"][0])))
+        q.put((rank, block.numpy(), block_np, local_stats.numpy(), stats.numpy(), int(aux_np["num_visible"][0]),
+               block_c.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -93,7 +101,7 @@ def test_view_sharded_allreduce_gloo_world2():
     from brush_amd import dist as BD
     from brush_amd.render import grad_block_layout
 
-    n, w, h, deg, world = 3000, 96, 64, 1, 2
+    n, w, h, deg, world = 3000, 96, 64, 3, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -118,6 +126,16 @@ def test_view_sharded_allreduce_gloo_world2():
         assert np.array_equal(reduced[prefix:], local[prefix:]), "v_xy (per-view statistic) must not be reduced"
         # the two views differ, so the reduce really changed something
         assert not np.array_equal(reduced[:prefix], local[:prefix])
+    # the compact exchange gives the same dense sum (f32 summation order / one extra rounding aside)
+    layout, _ = grad_block_layout(n, ncoef)
+    for r in range(world):
+        compact = res[r][5]
+        for name in ("v_means", "v_scales", "v_quats", "v_opac", "v_sh"):
+            off, sz = layout[name]
+            a, b = compact[off:off + sz].astype(np.float64), want[off:off + sz].astype(np.float64)
+            scale = np.abs(b).max() + 1e-30
+            assert np.abs(a - b).max() <= 2e-6 * scale, (name, np.abs(a - b).max(), scale)
+        assert np.array_equal(compact[prefix:], res[r][1][prefix:])
     # densification stats: sums over views; visibility row counts views in which a splat is visible
     s_sum = res[0][2] + res[1][2]
     assert np.allclose(res[0][3], s_sum) and np.allclose(res[1][3], s_sum)

@@ -418,6 +418,98 @@ def test_rejects_bad_shapes(dev):
                                 torch.zeros((n, 5, 3), device=dev), ok["raw"])
 
 
+def test_degenerate_parameters_stay_in_bounds(dev):
+    """NaN / inf / zero / huge parameters (the reference runs its kernels unchecked,
+    crates/brush-kernel `execute_unchecked`): every index in this build is clamped or capacity
+    checked, so the op must complete with sane counts and leave healthy splats' pixels finite."""
+    import torch
+
+    import brush_amd
+
+    n, w, h = 3000, 160, 96
+    cloud = H.synthetic_cloud(n, 1, seed=13, mean_mult=0.002)
+    bad = np.arange(0, 200)
+    cloud["means"][bad[0:20]] = np.nan
+    cloud["means"][bad[20:40]] = np.inf
+    cloud["means"][bad[40:60], 2] = -8.0 + 0.0100001          # grazing the near cull plane
+    cloud["log_scales"][bad[60:80]] = 80.0                     # exp overflows to inf
+    cloud["log_scales"][bad[80:100]] = -120.0                  # exp underflows to 0
+    cloud["log_scales"][bad[100:110]] = np.nan
+    cloud["quats"][bad[110:130]] = 0.0
+    cloud["quats"][bad[130:140]] = np.nan
+    cloud["raw_opac"][bad[140:160]] = 1e30
+    cloud["raw_opac"][bad[160:170]] = -1e30
+    cloud["raw_opac"][bad[170:180]] = np.nan
+    cloud["sh"][bad[180:200]] = np.inf
+    p = {k: _t(v, dev, grad=True) for k, v in cloud.items()}
+    xy = torch.zeros((n, 2), device=dev, requires_grad=True)
+    out, aux = brush_amd.render_splats(_camera(w, h), (w, h), p["means"], xy, p["log_scales"], p["quats"], p["sh"],
+                                       p["raw_opac"], False, 200_000)
+    out.nan_to_num().sum().backward()
+    torch.cuda.synchronize()
+    V, I = aux.read_num_visible(), aux.read_num_intersections()
+    assert 0 < V <= n and 0 < I <= aux.max_intersects
+    gfc = aux.global_from_compact_gid[:V].long()
+    assert int(gfc.max()) < n and int(torch.bincount(gfc, minlength=n).max()) == 1
+    bins = aux.tile_bins.long()
+    assert int(bins.max()) <= I and bool((bins[..., 1] >= bins[..., 0]).all())
+    assert int(aux.compact_gid_from_isect[:I].max()) < V
+    for g in (p["means"].grad, p["sh"].grad, xy.grad):
+        assert g is not None and g.shape[0] == n
+    # the same scene without the poisoned splats renders finite
+    keep = np.arange(200, n)
+    q = {k: _t(v[keep], dev) for k, v in cloud.items()}
+    clean, _ = brush_amd.render_splats(_camera(w, h), (w, h), q["means"], None, q["log_scales"], q["quats"], q["sh"],
+                                       q["raw_opac"], False, 200_000)
+    assert bool(torch.isfinite(clean).all())
+
+
+def test_compact_gradient_records_round_trip(dev):
+    """brush_amd.dist: the 60-byte records of the visible splats reproduce the op's dense gradient
+    block (the multi-GPU exchange all-gathers these instead of all-reducing 52+12C bytes/splat)."""
+    import torch
+
+    import brush_amd
+    from brush_amd import dist as BD
+    from brush_amd import render as R
+
+    n, w, h, deg = 50000, 320, 240, 3
+    C = (deg + 1) ** 2
+    cloud = H.synthetic_cloud(n, deg, seed=6, mean_mult=0.01)
+    p = {k: _t(v, dev) for k, v in cloud.items()}
+    out, aux, u = R._forward_impl(_camera(w, h), (w, h), p["means"], p["log_scales"], p["quats"], p["sh"],
+                                  p["raw_opac"], False, 2_000_000)
+    v_out = torch.randn((h, w, 4), device=dev) / (h * w)
+    g, block = R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], C, out, v_out)
+    V = aux.read_num_visible()
+    rows = -(-V // 256) * 256
+    rec = BD.pack_view_records(block, aux, n, C, rows)
+    cam = aux.uniforms_buffer[12:15].contiguous().view(torch.float32)[None]
+    rebuilt = torch.empty_like(block)
+    rebuilt.copy_(block)
+    BD.expand_view_records(rec[None], cam, p["means"], rebuilt, n, C)  # HIP kernel
+    ref = torch.empty_like(block)
+    ref.copy_(block)
+    BD.expand_view_records_torch(rec[None].repeat(3, 1, 1), cam.repeat(3, 1), p["means"], ref, n, C)
+    three = torch.empty_like(block)
+    three.copy_(block)
+    BD.expand_view_records(rec[None].repeat(3, 1, 1), cam.repeat(3, 1), p["means"], three, n, C)
+    pf = BD.param_grad_floats(n, C)
+    assert float((three[:pf].double() - ref[:pf].double()).abs().max()) <= 2e-6 * float(ref[:pf].abs().max())
+    # own_view form: the block keeps its own dense gradients, the two other (identical) views are added
+    own = torch.empty_like(block)
+    own.copy_(block)
+    BD.expand_view_records(rec[None].repeat(3, 1, 1), cam.repeat(3, 1), p["means"], own, n, C, own_view=1)
+    assert float((own[:pf].double() - ref[:pf].double()).abs().max()) <= 2e-6 * float(ref[:pf].abs().max())
+    layout, _ = R.grad_block_layout(n, C)
+    for name in ("v_means", "v_scales", "v_quats", "v_opac", "v_sh"):
+        off, sz = layout[name]
+        a, b = rebuilt[off:off + sz].double(), block[off:off + sz].double()
+        assert float((a - b).abs().max()) <= 2e-6 * (float(b.abs().max()) + 1e-30), name
+    off, sz = layout["v_xy"]
+    assert torch.equal(rebuilt[off:off + sz], block[off:off + sz])  # per-view statistic: untouched
+
+
 def test_training_steps_reduce_loss(dev):
     """the reference's step (L1 + 0.2*SSIM, five Adam groups, SH lerp) drives
     the op end to end; fitting a render of perturbed parameters must reduce the loss."""
