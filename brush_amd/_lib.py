@@ -75,8 +75,10 @@ _SYMBOLS = [
     ("brush_render_backward", C.c_int,
      [C.POINTER(BrushUniforms), C.POINTER(BrushAux), _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P,
       _P, _P, _P, C.c_size_t, _P]),
+    ("brush_pack_view_records", C.c_int,
+     [C.POINTER(BrushAux), C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_uint32, _P]),
     ("brush_expand_view_records", C.c_int,
-     [_P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+     [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     ("brush_profiler_create", C.c_int, [C.POINTER(_P)]),
     ("brush_profiler_destroy", None, [_P]),
     ("brush_profiler_attach", None, [_P]),

@@ -96,9 +96,34 @@ def sh_basis_torch(degree: int, d: torch.Tensor) -> torch.Tensor:
     return torch.stack(Y, dim=1)
 
 
+def _seg_ptr(block, layout, name):
+    return block.data_ptr() + layout[name][0] * 4
+
+
 def pack_view_records(block: torch.Tensor, aux: RenderAux, n: int, ncoef: int, rows: int) -> torch.Tensor:
-    """[rows, 16] f32 records of this view's visible splats (rows >= num_visible; tail rows have
-    column 15 == 0 and are ignored).  Column 0 carries the global id as int32 bits."""
+    """[rows, 16] f32 records of this view's visible splats through brush_pack_view_records (rows
+    beyond num_visible are left uninitialised; consumers use the per-view row counts)."""
+    import ctypes as C
+
+    from . import _lib
+
+    assert block.is_cuda, "brush_amd has no CPU path: tensors must live on the GPU"
+    layout, _ = grad_block_layout(n, ncoef)
+    rec = torch.empty((rows, _REC), dtype=torch.float32, device=block.device)
+    s = aux._as_struct()
+    degree = int(round(ncoef ** 0.5)) - 1
+    with torch.cuda.device(block.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().brush_pack_view_records(C.byref(s), n, degree, _seg_ptr(block, layout, "v_means"),
+                                                      _seg_ptr(block, layout, "v_scales"),
+                                                      _seg_ptr(block, layout, "v_quats"), _seg_ptr(block, layout, "v_opac"),
+                                                      _seg_ptr(block, layout, "v_sh"), rec.data_ptr(), rows, stream),
+                   "brush_pack_view_records")
+    return rec
+
+
+def pack_view_records_torch(block: torch.Tensor, aux: RenderAux, n: int, ncoef: int, rows: int) -> torch.Tensor:
+    """Plain-torch restatement of brush_pack_view_records (test reference; CPU gloo test)."""
     layout, _ = grad_block_layout(n, ncoef)
     dev = block.device
     idx = torch.arange(rows, device=dev)
@@ -116,53 +141,51 @@ def pack_view_records(block: torch.Tensor, aux: RenderAux, n: int, ncoef: int, r
     rec[:, 7:11] = seg("v_quats", 4)[gid]
     rec[:, 11] = seg("v_opac", 1)[gid, 0]
     rec[:, 12:15] = seg("v_sh", ncoef * 3)[gid, 0:3]
-    rec[:, 15] = valid.to(torch.float32)
+    rec[:, 15] = 1.0
     return rec
 
 
-def expand_view_records(recs: torch.Tensor, campos: torch.Tensor, means: torch.Tensor, block: torch.Tensor,
-                        n: int, ncoef: int, own_view: Optional[int] = None) -> torch.Tensor:
-    """Sums the records of the views ([W, rows, 16], camera terms [W, 3] = viewmat[3].xyz of each
-    view) into the parameter prefix of `block` with the HIP kernel brush_expand_view_records.
-    own_view=None: the prefix is overwritten by the sum of all W views; own_view=r: `block` already
-    holds view r's dense gradients and the other views are added on top.  Device tensors only (no
-    CPU path); the torch restatement below is the test reference."""
-    import ctypes as C
-
+def expand_view_records(recs: torch.Tensor, view_rows: torch.Tensor, campos: torch.Tensor, means: torch.Tensor,
+                        block: torch.Tensor, n: int, ncoef: int, own_view: Optional[int] = None) -> torch.Tensor:
+    """Sums the records of the views (recs [W, rows, 16], valid rows per view `view_rows` int32 [W],
+    camera terms [W, 3] = viewmat[3].xyz of each view) into the parameter prefix of `block` with the
+    HIP kernel brush_expand_view_records.  own_view=None: the prefix is overwritten by the sum of
+    all W views; own_view=r: `block` already holds view r's dense gradients and the other views
+    are added on top.  Device tensors only (no CPU path)."""
     from . import _lib
 
     assert block.is_cuda and recs.is_cuda and means.is_cuda, "brush_amd has no CPU path: tensors must live on the GPU"
     layout, _ = grad_block_layout(n, ncoef)
     W, rows, _ = recs.shape
     recs, campos, means = recs.contiguous(), campos.contiguous(), means.contiguous()
-
-    def ptr(name):
-        off, _sz = layout[name]
-        return block.data_ptr() + off * 4
-
+    view_rows = view_rows.to(torch.int32).contiguous()
     degree = int(round(ncoef ** 0.5)) - 1
     with torch.cuda.device(block.device):
         stream = torch.cuda.current_stream().cuda_stream
         skip = 0xFFFFFFFF if own_view is None else int(own_view)
-        _lib.check(_lib.lib().brush_expand_view_records(recs.data_ptr(), W * rows, rows, campos.data_ptr(),
-                                                        means.data_ptr(), n, degree, skip, ptr("v_means"), ptr("v_scales"),
-                                                        ptr("v_quats"), ptr("v_opac"), ptr("v_sh"), stream),
+        _lib.check(_lib.lib().brush_expand_view_records(recs.data_ptr(), W * rows, rows, view_rows.data_ptr(),
+                                                        campos.data_ptr(), means.data_ptr(), n, degree, skip,
+                                                        _seg_ptr(block, layout, "v_means"), _seg_ptr(block, layout, "v_scales"),
+                                                        _seg_ptr(block, layout, "v_quats"), _seg_ptr(block, layout, "v_opac"),
+                                                        _seg_ptr(block, layout, "v_sh"), stream),
                    "brush_expand_view_records")
     return block
 
 
-def expand_view_records_torch(recs: torch.Tensor, campos: torch.Tensor, means: torch.Tensor, block: torch.Tensor,
-                              n: int, ncoef: int, own_view: Optional[int] = None) -> torch.Tensor:
-    """Plain-torch restatement of brush_expand_view_records (reference for the tests; also what the
-    world_size-2 gloo test on CPU uses)."""
+def expand_view_records_torch(recs: torch.Tensor, view_rows: torch.Tensor, campos: torch.Tensor, means: torch.Tensor,
+                              block: torch.Tensor, n: int, ncoef: int, own_view: Optional[int] = None) -> torch.Tensor:
+    """Plain-torch restatement of brush_expand_view_records (test reference; CPU gloo test)."""
     layout, _ = grad_block_layout(n, ncoef)
     W, rows, _ = recs.shape
     flat = recs.reshape(W * rows, _REC)
-    keep = flat[:, 15] > 0.5
+    ridx = torch.arange(W * rows, device=flat.device)
+    view = ridx // rows
+    keep = (ridx - view * rows) < view_rows.to(ridx.dtype)[view]
     if own_view is not None:
-        keep = keep & (torch.arange(W * rows, device=flat.device) // rows != own_view)
+        keep = keep & (view != own_view)
     gid = flat[:, 0].contiguous().view(torch.int32).long()
     gid = torch.where(keep, gid, torch.zeros_like(gid))
+    flat = torch.where(keep[:, None], flat, torch.zeros_like(flat))  # rows beyond a view's count are garbage
     w = keep.to(torch.float32)[:, None]
     cam = campos.repeat_interleave(rows, dim=0)
     d = means[gid] - cam
@@ -171,7 +194,6 @@ def expand_view_records_torch(recs: torch.Tensor, campos: torch.Tensor, means: t
     Y = sh_basis_torch(degree, d)                        # [M, C]
     rgb = flat[:, 12:15] * (w / _SH_C0)                  # v_rgb = v_sh0 / Y0 (0 for padding rows)
     Y = torch.where(keep[:, None], Y, torch.zeros_like(Y))  # padding rows may have NaN dirs
-
     if own_view is None:
         block[:param_grad_floats(n, ncoef)].zero_()
 
@@ -188,22 +210,24 @@ def expand_view_records_torch(recs: torch.Tensor, campos: torch.Tensor, means: t
 
 
 def allreduce_param_grads_compact(block: torch.Tensor, aux: RenderAux, means: torch.Tensor, n: int, ncoef: int,
-                                  group: Optional[dist.ProcessGroup] = None, expand=None) -> torch.Tensor:
-    """Same result as allreduce_param_grads (sum over views, every rank) through an all-gather of
-    compact per-view records.  One small all-reduce(MAX) + host read sizes the padded exchange."""
+                                  group: Optional[dist.ProcessGroup] = None, pack=None, expand=None) -> torch.Tensor:
+    """Same result as allreduce_param_grads (sum over views, on every rank) through an all-gather of
+    compact per-view records.  One all-gather of the per-view counts (with a host read) sizes the
+    padded record exchange."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return block
-    world = dist.get_world_size(group)
-    vmax = aux.num_visible.to(torch.int64).clone()
-    dist.all_reduce(vmax, op=dist.ReduceOp.MAX, group=group)
-    rows = max(256, -(-int(vmax.item()) // 256) * 256)
-    rec = pack_view_records(block, aux, n, ncoef, rows)
-    words = aux.uniforms_buffer[12:15].contiguous().view(torch.float32)  # viewmat[3].xyz (SURVEY §2b-1)
-    recs = torch.empty((world, rows, _REC), dtype=torch.float32, device=block.device)
-    cams = torch.empty((world, 3), dtype=torch.float32, device=block.device)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = block.device
+    counts = torch.empty(world, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(counts, aux.num_visible.reshape(-1)[:1].to(torch.int32).clone(), group=group)
+    rows = max(256, -(-int(counts.max().item()) // 256) * 256)
+    rec = (pack or pack_view_records)(block, aux, n, ncoef, rows)
+    words = aux.uniforms_buffer[12:15].contiguous().view(torch.float32).clone()  # viewmat[3].xyz (SURVEY §2b-1)
+    recs = torch.empty((world, rows, _REC), dtype=torch.float32, device=dev)
+    cams = torch.empty((world, 3), dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(recs.view(-1), rec.view(-1), group=group)
-    dist.all_gather_into_tensor(cams.view(-1), words.clone(), group=group)
-    return (expand or expand_view_records)(recs, cams, means, block, n, ncoef, dist.get_rank(group))
+    dist.all_gather_into_tensor(cams.view(-1), words, group=group)
+    return (expand or expand_view_records)(recs, counts, cams, means, block, n, ncoef, rank)
 
 
 def densification_stats(v_xy: torch.Tensor, aux: RenderAux, img_size) -> torch.Tensor:

@@ -139,19 +139,27 @@ int brush_render_backward(const BrushUniforms *h_uniforms, const BrushAux *h_aux
                           size_t workspace_bytes, brush_stream_t stream);
 
 /* ---- multi-GPU gradient exchange (build extension; the reference is single-device) ------- */
-/* Sums the compact gradient records of W views into the dense parameter-gradient arrays.
+/* Record layout (16 f32 = 64 bytes per visible splat of one view):
+ *   [gid as u32 bits | v_means(3) | v_scales(3) | v_quats(4) | v_opac | v_sh[gid,0,:](3) | 1.0]
+ * brush_pack_view_records writes rows c < min(num_visible, max_rows) of `records` (compact = depth
+ * order) from the dense gradients of brush_render_backward; rows beyond are left untouched. */
+int brush_pack_view_records(const BrushAux *h_aux, uint32_t n, uint32_t sh_degree, const float *v_means,
+                            const float *v_scales, const float *v_quats, const float *v_opac,
+                            const float *v_sh, float *records, uint32_t max_rows, brush_stream_t stream);
+/* Sums the records of W views into the dense parameter-gradient arrays.  records:
+ * [W * rows_per_view][16]; view v owns rows [v*rows_per_view, v*rows_per_view + view_rows[v])
+ * (view_rows: device array [W]); campos: [W][3] = viewmat[3].xyz of each view (the term the
+ * reference uses as camera position, project_visible.wgsl:232-233); means: [N,3].  The SH rows are
+ * rebuilt as Y(normalize(mean - campos)) (x) v_sh0 / Y0 (gather_grads.wgsl:186-222).
  * skip_view = 0xFFFFFFFF: the arrays are zero-filled first and all W views are added;
  * skip_view = r: the arrays are expected to hold view r's dense gradients already (the caller's
- * own backward output) and the other W-1 views are added on top.  records: [num_records][16] f32 =
- *   [gid as u32 bits | v_means(3) | v_scales(3) | v_quats(4) | v_opac | v_sh[gid,0,:](3) | valid],
- * view of record r = r / rows_per_view; campos: [W][3] = viewmat[3].xyz of each view (the term the
- * reference uses as camera position, project_visible.wgsl:232-233); means: [N,3].  The SH rows are
- * rebuilt as Y(normalize(mean - campos)) (x) v_sh0 / Y0 (gather_grads.wgsl:186-222).  See
- * brush_amd/dist.py for the all-gather that produces `records`. */
+ * own backward output) and the other W-1 views are added on top.  brush_amd/dist.py shows the
+ * RCCL all-gather that produces `records`. */
 int brush_expand_view_records(const float *records, uint32_t num_records, uint32_t rows_per_view,
-                              const float *campos, const float *means, uint32_t n, uint32_t sh_degree,
-                              uint32_t skip_view, float *v_means, float *v_scales, float *v_quats,
-                              float *v_opac, float *v_sh, brush_stream_t stream);
+                              const uint32_t *view_rows, const float *campos, const float *means,
+                              uint32_t n, uint32_t sh_degree, uint32_t skip_view, float *v_means,
+                              float *v_scales, float *v_quats, float *v_opac, float *v_sh,
+                              brush_stream_t stream);
 
 /* ---- opt-in stage timing ---------------------------------------------------------------- */
 /* Counterpart of the reference's tracing spans + sync-span layer (render.rs:69-267,474-577;

@@ -86,7 +86,7 @@ def _worker(rank, world, port, n, w, h, deg, q):
         aux.uniforms_buffer = ub
         block_c = torch.from_numpy(block_np.copy())
         BD.allreduce_param_grads_compact(block_c, aux, torch.from_numpy(cloud["means"]), n, ncoef,
-                                         expand=BD.expand_view_records_torch)
+                                         pack=BD.pack_view_records_torch, expand=BD.expand_view_records_torch)
         stats = BD.densification_stats(torch.from_numpy(g["v_xy"]), aux, (w, h))
         local_stats = stats.clone()
         BD.allreduce_densification_stats(stats)

@@ -483,24 +483,27 @@ def test_compact_gradient_records_round_trip(dev):
     g, block = R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], C, out, v_out)
     V = aux.read_num_visible()
     rows = -(-V // 256) * 256
-    rec = BD.pack_view_records(block, aux, n, C, rows)
+    rec = BD.pack_view_records(block, aux, n, C, rows)          # HIP
+    rec_ref = BD.pack_view_records_torch(block, aux, n, C, rows)
+    assert torch.equal(rec[:V].view(torch.int32), rec_ref[:V].view(torch.int32))
     cam = aux.uniforms_buffer[12:15].contiguous().view(torch.float32)[None]
-    rebuilt = torch.empty_like(block)
-    rebuilt.copy_(block)
-    BD.expand_view_records(rec[None], cam, p["means"], rebuilt, n, C)  # HIP kernel
-    ref = torch.empty_like(block)
-    ref.copy_(block)
-    BD.expand_view_records_torch(rec[None].repeat(3, 1, 1), cam.repeat(3, 1), p["means"], ref, n, C)
-    three = torch.empty_like(block)
-    three.copy_(block)
-    BD.expand_view_records(rec[None].repeat(3, 1, 1), cam.repeat(3, 1), p["means"], three, n, C)
+    one = torch.tensor([V], dtype=torch.int32, device=dev)
+    rebuilt = block.clone()
+    BD.expand_view_records(rec[None], one, cam, p["means"], rebuilt, n, C)  # HIP kernel, overwrite form
+    three_rows = torch.tensor([V, V - 7, V], dtype=torch.int32, device=dev)
+    ref = block.clone()
+    BD.expand_view_records_torch(rec[None].repeat(3, 1, 1), three_rows, cam.repeat(3, 1), p["means"], ref, n, C)
+    three = block.clone()
+    BD.expand_view_records(rec[None].repeat(3, 1, 1), three_rows, cam.repeat(3, 1), p["means"], three, n, C)
     pf = BD.param_grad_floats(n, C)
     assert float((three[:pf].double() - ref[:pf].double()).abs().max()) <= 2e-6 * float(ref[:pf].abs().max())
-    # own_view form: the block keeps its own dense gradients, the two other (identical) views are added
-    own = torch.empty_like(block)
-    own.copy_(block)
-    BD.expand_view_records(rec[None].repeat(3, 1, 1), cam.repeat(3, 1), p["means"], own, n, C, own_view=1)
-    assert float((own[:pf].double() - ref[:pf].double()).abs().max()) <= 2e-6 * float(ref[:pf].abs().max())
+    # own_view form: the block keeps its own dense gradients, the two other views are added on top
+    own_ref = block.clone()
+    BD.expand_view_records_torch(rec[None].repeat(3, 1, 1), three_rows, cam.repeat(3, 1), p["means"], own_ref, n, C,
+                                 own_view=0)
+    own = block.clone()
+    BD.expand_view_records(rec[None].repeat(3, 1, 1), three_rows, cam.repeat(3, 1), p["means"], own, n, C, own_view=0)
+    assert float((own[:pf].double() - own_ref[:pf].double()).abs().max()) <= 2e-6 * float(own_ref[:pf].abs().max())
     layout, _ = R.grad_block_layout(n, C)
     for name in ("v_means", "v_scales", "v_quats", "v_opac", "v_sh"):
         off, sz = layout[name]
