@@ -47,6 +47,17 @@ class BrushAux(C.Structure):
     ]
 
 
+class BrushAdamConfig(C.Structure):
+    """Hyper-parameters of brush_adam_step (train.rs:184,275-282,336-351)."""
+    _fields_ = [
+        ("lr_mean", C.c_float), ("lr_scale", C.c_float), ("lr_rotation", C.c_float), ("lr_opac", C.c_float),
+        ("lr_coeffs_dc", C.c_float), ("sh_rest_lerp", C.c_float),
+        ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float),
+        ("time", C.c_uint32),
+        ("rotation_grad_wrt_normalized", C.c_uint32),
+    ]
+
+
 class BrushError(RuntimeError):
     pass
 
@@ -79,6 +90,14 @@ _SYMBOLS = [
      [C.POINTER(BrushAux), C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_uint32, _P]),
     ("brush_expand_view_records", C.c_int,
      [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    ("brush_loss_workspace_size", C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
+    ("brush_l1_ssim_loss", C.c_int,
+     [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_float, _P, _P, _P, C.c_size_t, _P]),
+    ("brush_adam_step", C.c_int,
+     [C.POINTER(BrushAdamConfig), C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("brush_normalize_quats", C.c_int, [_P, _P, C.c_uint32, _P]),
+    ("brush_refine_stats", C.c_int,
+     [C.POINTER(BrushAux), _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
     ("brush_profiler_create", C.c_int, [C.POINTER(_P)]),
     ("brush_profiler_destroy", None, [_P]),
     ("brush_profiler_attach", None, [_P]),

@@ -1,0 +1,467 @@
+// train_step.hip — the parts of the reference's training iteration that sit either side of the op
+// (SURVEY §8(f) row 1): the image loss with its gradient, the optimizer step and the screen-space
+// gradient statistics.  The reference expresses these as Burn tensor ops (≈60 launches); here each is
+// one or two HBM-streaming kernels.
+//
+//   k_ssim_forward / k_ssim_backward : loss = L1*(1-w) - SSIM*w (train.rs:243-268) with the SSIM of
+//       ssim.rs:42-101 (11x11 Gaussian window sigma 1.5, zero padding div_ceil(11,2) = 6, so the SSIM
+//       map is (h+2)x(w+2); variances clamped at 0) and d loss / d pred.  The window is outer(g, g), so
+//       every blur is two 1-D passes through LDS (same linear operator, ssim.rs:17-32 notes it as a TODO).
+//   k_adam : Adam with the reference's five learning rates and the SH-rest lerp (train.rs:318-359) over
+//       the contiguous gradient block the backward writes; update rule of burn 0.16 `Adam::step`
+//       (m/(1-b1^t) / (sqrt(v/(1-b2^t)) + eps)), eps = 1e-15 (train.rs:184).
+//   k_refine_stats : train.rs:284-316.
+// Roofline: HBM streaming (loss ≈ 150 B/pixel, Adam 28 B/parameter).
+#include "internal.hpp"
+
+namespace brush {
+namespace {
+
+constexpr int kWin = 11;        // ssim window (TrainConfig::ssim_window_size default, train.rs:63)
+constexpr int kPad = 6;         // div_ceil(11, 2), ssim.rs:49
+constexpr int kOutCols = 54;    // columns a wave produces: 64 lanes minus the 10-column halo
+constexpr int kSegRows = 34;    // rows a block produces: 34 + 10 halo = 4 * 11 marched rows
+constexpr int kRowBuf = 80;     // floats per LDS row buffer (lane + 10 taps < 74)
+constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
+
+struct Window {
+    float g[kWin];
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Sum over the 256 threads of a block in a fixed order (deterministic); valid in thread 0.
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    v = wave_sum(v);
+    if (lane_id() == 0) red[threadIdx.x / kWave] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+// LDS traffic inside one wave is in order; this only stops the compiler from moving accesses.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Both loss kernels march a wave down a strip of 64 columns for one colour channel (wave = channel,
+// block = 3 waves).  Per marched row: the lane's value goes to a per-wave LDS row buffer, the
+// 11-tap horizontal blur is read back from it (lane + k), and the vertical blur runs over a ring
+// of the last 11 blurred rows kept in registers (the 11-fold unrolled loop makes the ring static).
+// No block barrier, 2 KB of LDS per block: occupancy is bounded by registers only.
+
+// SSIM map position (oy, ox) for oy in the block's 34 rows, ox in the wave's 54 columns: writes the
+// three derivative maps (wrt blur(a), blur(a*a), blur(a*b); a = pred, b = gt) scaled by `coef`, and
+// per-wave partial sums of the SSIM map and of |pred - gt| (each input pixel owned by the wave
+// holding map position (iy+1, ix+1)).
+__global__ __launch_bounds__(192) void k_ssim_forward(const float *__restrict__ pred, const float *__restrict__ gt,
+                                                      uint32_t gt_channels, uint32_t w, uint32_t h, Window win,
+                                                      float coef, float *__restrict__ dmaps,
+                                                      float *__restrict__ partials) {
+    __shared__ float rows[3][2][kRowBuf];
+    const int ch = threadIdx.x / kWave, l = lane_id();
+    float *ra = rows[ch][0], *rb = rows[ch][1];
+    const int W2 = w + 2, H2 = h + 2;
+    const int x0 = blockIdx.x * kOutCols, oy0 = blockIdx.y * kSegRows;
+    const int ix = x0 - kPad + l;
+    const bool col_ok = ix >= 0 && ix < (int)w;
+    const int ox = x0 + l;
+    const bool out_col = l < kOutCols && ox < W2;
+    const bool own_col = l >= kPad - 1 && l < kPad - 1 + kOutCols;
+    const size_t plane = (size_t)W2 * H2;
+    float hq[kWin][5];
+    float msum = 0.0f, l1 = 0.0f;
+    for (int r0 = 0; r0 < kSegRows + kWin - 1; r0 += kWin) {
+#pragma unroll
+        for (int j = 0; j < kWin; j++) {
+            const int r = r0 + j;
+            const int iy = oy0 - kPad + r;
+            float a = 0.0f, b = 0.0f;
+            if (col_ok && iy >= 0 && iy < (int)h) {
+                const size_t px = (size_t)iy * w + ix;
+                a = pred[px * 4 + ch];
+                b = gt[px * gt_channels + ch];
+                if (own_col && r >= kPad - 1 && r < kPad - 1 + kSegRows) {
+                    l1 += fabsf(a - b);
+                    if (ch == 0 && gt_channels == 4) l1 += fabsf(pred[px * 4 + 3] - gt[px * 4 + 3]);
+                }
+            }
+            ra[l] = a, rb[l] = b;
+            wave_lds_sync();
+            float sa = 0.f, sb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+#pragma unroll
+            for (int k = 0; k < kWin; k++) {
+                const float av = ra[l + k], bv = rb[l + k];
+                const float ga = win.g[k] * av, gb = win.g[k] * bv;
+                sa += ga, sb += gb, saa += ga * av, sbb += gb * bv, sab += ga * bv;
+            }
+            wave_lds_sync();
+            hq[j][0] = sa, hq[j][1] = sb, hq[j][2] = saa, hq[j][3] = sbb, hq[j][4] = sab;
+            const int oy = oy0 + r - (kWin - 1);
+            if (r >= kWin - 1 && oy < H2) {  // ring slot of marched row r - 10 + k is (j + 1 + k) % 11
+                float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < kWin; k++) {
+#pragma unroll
+                    for (int q = 0; q < 5; q++) v[q] += win.g[k] * hq[(j + 1 + k) % kWin][q];
+                }
+                if (out_col) {
+                    const float mx = v[0], my = v[1];
+                    const float mu_xx = mx * mx, mu_yy = my * my, mu_xy = mx * my;
+                    const float sxx_raw = v[2] - mu_xx;
+                    const float sxx = fmaxf(sxx_raw, 0.0f), syy = fmaxf(v[3] - mu_yy, 0.0f), sxy = v[4] - mu_xy;
+                    const float A1 = mu_xy * 2.0f + kC1, A2 = sxy * 2.0f + kC2;
+                    const float B1 = mu_xx + mu_yy + kC1, B2 = sxx + syy + kC2;
+                    const float inv = 1.0f / (B1 * B2);
+                    const float m = A1 * A2 * inv;
+                    msum += m;
+                    const float d_eab = 2.0f * A1 * inv;
+                    const float d_eaa = sxx_raw >= 0.0f ? -m / B2 : 0.0f;  // clamp_min(0) passes the gradient at >= 0
+                    const float d_mu = 2.0f * my * (A2 - A1) * inv - 2.0f * mx * (m / B1) - 2.0f * mx * d_eaa;
+                    const size_t o = (size_t)oy * W2 + ox;
+                    dmaps[(0 * 3 + ch) * plane + o] = d_mu * coef;
+                    dmaps[(1 * 3 + ch) * plane + o] = d_eaa * coef;
+                    dmaps[(2 * 3 + ch) * plane + o] = d_eab * coef;
+                }
+            }
+        }
+    }
+    msum = wave_sum(msum), l1 = wave_sum(l1);
+    const uint32_t nwave = gridDim.x * gridDim.y * 3, wv = (blockIdx.y * gridDim.x + blockIdx.x) * 3 + ch;
+    if (l == 0) partials[wv] = msum, partials[nwave + wv] = l1;
+}
+
+// Image position (py, px): T[X](p) = sum_j g[j] X[p - 4 + j] per axis (the transposed blur; g is
+// symmetric) of the three derivative maps, combined with the L1 term into d loss / d pred.  Wave 0
+// of block (0,0) also reduces the partial sums into the loss value.
+__global__ __launch_bounds__(192) void k_ssim_backward(const float *__restrict__ pred, const float *__restrict__ gt,
+                                                       uint32_t gt_channels, uint32_t w, uint32_t h, Window win,
+                                                       const float *__restrict__ dmaps, float l1_coef,
+                                                       float *__restrict__ v_pred, const float *__restrict__ partials,
+                                                       uint32_t nwave_fwd, float l1_weight, float ssim_weight,
+                                                       float inv_l1_count, float inv_ssim_count,
+                                                       float *__restrict__ loss) {
+    __shared__ float rows[3][3][kRowBuf];
+    const int ch = threadIdx.x / kWave, l = lane_id();
+    const int W2 = w + 2, H2 = h + 2;
+    const int px0 = blockIdx.x * kOutCols, py0 = blockIdx.y * kSegRows;
+    constexpr int kOff = kWin - 1 - kPad;  // 4
+    const int ox = px0 - kOff + l;
+    const bool col_ok = ox >= 0 && ox < W2;
+    const int px = px0 + l;
+    const bool out_col = l < kOutCols && px < (int)w;
+    const size_t plane = (size_t)W2 * H2;
+    const float *d0 = dmaps + (0 * 3 + ch) * plane, *d1 = dmaps + (1 * 3 + ch) * plane, *d2 = dmaps + (2 * 3 + ch) * plane;
+    auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };
+    float hq[kWin][3];
+    for (int r0 = 0; r0 < kSegRows + kWin - 1; r0 += kWin) {
+#pragma unroll
+        for (int j = 0; j < kWin; j++) {
+            const int r = r0 + j;
+            const int oy = py0 - kOff + r;
+            float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f;
+            if (col_ok && oy >= 0 && oy < H2) {
+                const size_t o = (size_t)oy * W2 + ox;
+                x0 = d0[o], x1 = d1[o], x2 = d2[o];
+            }
+            rows[ch][0][l] = x0, rows[ch][1][l] = x1, rows[ch][2][l] = x2;
+            wave_lds_sync();
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < kWin; k++) {
+                s0 += win.g[k] * rows[ch][0][l + k];
+                s1 += win.g[k] * rows[ch][1][l + k];
+                s2 += win.g[k] * rows[ch][2][l + k];
+            }
+            wave_lds_sync();
+            hq[j][0] = s0, hq[j][1] = s1, hq[j][2] = s2;
+            const int py = py0 + r - (kWin - 1);
+            if (r >= kWin - 1 && py < (int)h && out_col) {
+                float t[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < kWin; k++) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) t[q] += win.g[k] * hq[(j + 1 + k) % kWin][q];
+                }
+                const size_t p = (size_t)py * w + px;
+                const float a = pred[p * 4 + ch], b = gt[p * gt_channels + ch];
+                v_pred[p * 4 + ch] = t[0] + 2.0f * a * t[1] + b * t[2] + l1_coef * sgn(a - b);
+                if (ch == 0)  // alpha: compared only when the target has alpha (train.rs:248-252)
+                    v_pred[p * 4 + 3] = gt_channels == 4 ? l1_coef * sgn(pred[p * 4 + 3] - gt[p * 4 + 3]) : 0.0f;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && ch == 0) {
+        float ms = 0.0f, ls = 0.0f;
+        for (uint32_t i = l; i < nwave_fwd; i += kWave) ms += partials[i], ls += partials[nwave_fwd + i];
+        ms = wave_sum(ms), ls = wave_sum(ls);
+        if (l == 0) loss[0] = ls * inv_l1_count * l1_weight - ms * inv_ssim_count * ssim_weight;
+    }
+}
+
+// L1-only form (ssim_weight == 0, train.rs:254-266): one thread per pixel.
+__global__ __launch_bounds__(256) void k_l1_backward(const float4 *__restrict__ pred, const float *__restrict__ gt,
+                                                     uint32_t gt_channels, uint32_t npix, float l1_coef,
+                                                     float4 *__restrict__ v_pred, float *__restrict__ partials) {
+    __shared__ float red[4];
+    float l1 = 0.0f;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        const float4 p = pred[i];
+        const float *gp = gt + (size_t)i * gt_channels;
+        auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };
+        const float d0 = p.x - gp[0], d1 = p.y - gp[1], d2 = p.z - gp[2], d3 = gt_channels == 4 ? p.w - gp[3] : 0.0f;
+        l1 += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+        v_pred[i] = make_float4(l1_coef * sgn(d0), l1_coef * sgn(d1), l1_coef * sgn(d2), l1_coef * sgn(d3));
+    }
+    const float s = block_sum(l1, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(64) void k_l1_finalize(const float *__restrict__ partials, uint32_t nblk, float inv_count,
+                                                    float *__restrict__ loss) {
+    float s = 0.0f;
+    for (uint32_t i = threadIdx.x; i < nblk; i += kWave) s += partials[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss[0] = s * inv_count;
+}
+
+struct AdamArgs {
+    float lr[5];  // means, log_scales, quats, raw_opac, sh (dc)
+    float sh_lerp, beta1, beta2, eps, bc1, bc2;
+    uint32_t n, ncoef, quat_vjp;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_adam(AdamArgs a, float *__restrict__ means, float *__restrict__ log_scales,
+                                              float *__restrict__ quats, float *__restrict__ raw_opac,
+                                              float *__restrict__ sh, const float *__restrict__ g_means,
+                                              const float *__restrict__ g_scales, const float *__restrict__ g_quats,
+                                              const float *__restrict__ g_opac, const float *__restrict__ g_sh,
+                                              float *__restrict__ m1, float *__restrict__ m2, size_t total) {
+    const size_t n = a.n;
+    const size_t e0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (e0 >= total) return;
+    // segment of the moment arrays [means 3N | log_scales 3N | quats 4N | raw_opac N | sh 3CN]
+    float *p;
+    const float *grad;
+    float lr;
+    size_t rel;
+    bool is_sh = false, is_quat = false;
+    if (e0 < 3 * n) p = means, grad = g_means, rel = e0, lr = a.lr[0];
+    else if (e0 < 6 * n) p = log_scales, grad = g_scales, rel = e0 - 3 * n, lr = a.lr[1];
+    else if (e0 < 10 * n) p = quats, grad = g_quats, rel = e0 - 6 * n, lr = a.lr[2], is_quat = true;
+    else if (e0 < 11 * n) p = raw_opac, grad = g_opac, rel = e0 - 10 * n, lr = a.lr[3];
+    else p = sh, grad = g_sh, rel = e0 - 11 * n, lr = a.lr[4], is_sh = true;
+    float g[VEC], mo[VEC], ve[VEC], x[VEC];
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(g) = *reinterpret_cast<const float4 *>(grad + rel);
+        *reinterpret_cast<float4 *>(mo) = *reinterpret_cast<const float4 *>(m1 + e0);
+        *reinterpret_cast<float4 *>(ve) = *reinterpret_cast<const float4 *>(m2 + e0);
+        *reinterpret_cast<float4 *>(x) = *reinterpret_cast<const float4 *>(p + rel);
+    } else {
+        g[0] = grad[rel], mo[0] = m1[e0], ve[0] = m2[e0], x[0] = p[rel];
+    }
+    if (is_quat && a.quat_vjp) {
+        // The op was fed rot / |rot| (gaussian_splats.rs:174-175): chain v_q back to the raw rotation,
+        // v_rot = v_q / s - rot * (v_q . rot) / s^3 with s = |rot|.
+        if constexpr (VEC == 4) {
+            const float s2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+            const float inv_s = 1.0f / sqrtf(s2);
+            const float dot = (g[0] * x[0] + g[1] * x[1] + g[2] * x[2] + g[3] * x[3]) * (inv_s * inv_s * inv_s);
+#pragma unroll
+            for (int i = 0; i < 4; i++) g[i] = g[i] * inv_s - x[i] * dot;
+        } else {
+            // scalar layout: the thread of component 0 updates the whole quaternion (the other three
+            // must not read components a neighbour is rewriting)
+            if (rel & 3) return;
+            float q[4], vq[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) q[i] = p[rel + i], vq[i] = grad[rel + i];
+            const float s2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+            const float inv_s = 1.0f / sqrtf(s2);
+            const float dot = (vq[0] * q[0] + vq[1] * q[1] + vq[2] * q[2] + vq[3] * q[3]) * (inv_s * inv_s * inv_s);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float gi = vq[i] * inv_s - q[i] * dot;
+                const float mi = m1[e0 + i] * a.beta1 + gi * (1.0f - a.beta1);
+                const float vi = m2[e0 + i] * a.beta2 + (gi * gi) * (1.0f - a.beta2);
+                m1[e0 + i] = mi, m2[e0 + i] = vi;
+                p[rel + i] = q[i] - ((mi / a.bc1) / (sqrtf(vi / a.bc2) + a.eps)) * lr;
+            }
+            return;
+        }
+    }
+    const uint32_t row = 3 * a.ncoef;
+    uint32_t k = is_sh ? (uint32_t)(rel % row) : 0;
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+        mo[i] = mo[i] * a.beta1 + g[i] * (1.0f - a.beta1);
+        ve[i] = ve[i] * a.beta2 + (g[i] * g[i]) * (1.0f - a.beta2);
+        const float delta = (mo[i] / a.bc1) / (sqrtf(ve[i] / a.bc2) + a.eps);
+        const float stepped = x[i] - delta * lr;
+        // higher-order SH: lerp(old, stepped, 1/lr_coeffs_sh_scale), train.rs:336-351
+        x[i] = (is_sh && k >= 3) ? x[i] * (1.0f - a.sh_lerp) + stepped * a.sh_lerp : stepped;
+        k = k + 1 == row ? 0 : k + 1;
+    }
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(m1 + e0) = *reinterpret_cast<float4 *>(mo);
+        *reinterpret_cast<float4 *>(m2 + e0) = *reinterpret_cast<float4 *>(ve);
+        *reinterpret_cast<float4 *>(p + rel) = *reinterpret_cast<float4 *>(x);
+    } else {
+        m1[e0] = mo[0], m2[e0] = ve[0], p[rel] = x[0];
+    }
+}
+
+// gaussian_splats.rs:174-175: the op is fed rotation / |rotation|.
+__global__ __launch_bounds__(256) void k_normalize_quats(const float4 *__restrict__ rot, float4 *__restrict__ out,
+                                                         uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = rot[i];
+    const float s = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    out[i] = make_float4(q.x / s, q.y / s, q.z / s, q.w / s);
+}
+
+__global__ __launch_bounds__(256) void k_refine_stats(const uint32_t *__restrict__ num_visible,
+                                                      const uint32_t *__restrict__ global_from_compact,
+                                                      const float2 *__restrict__ v_xy, uint32_t n, float half_w,
+                                                      float half_h, float *__restrict__ grad_2d_accum,
+                                                      float *__restrict__ xy_grad_counts) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 v = v_xy[i];
+    const float vx = v.x * half_w, vy = v.y * half_h;
+    grad_2d_accum[i] += sqrtf(vx * vx + vy * vy);
+    if (i < min(*num_visible, n)) {
+        const uint32_t g = global_from_compact[i];  // distinct per compact id: plain read-modify-write
+        if (g < n) xy_grad_counts[g] += 1.0f;
+    }
+}
+
+Window make_window() {
+    Window win;
+    float sum = 0.0f;
+    for (int i = 0; i < kWin; i++) {
+        const float d = (float)i - (float)(kWin / 2);
+        win.g[i] = expf(-(d * d) / (2.0f * 1.5f * 1.5f));  // ssim.rs:7-14
+        sum += win.g[i];
+    }
+    for (int i = 0; i < kWin; i++) win.g[i] /= sum;
+    return win;
+}
+
+inline uint32_t loss_blocks_x(uint32_t w) { return ceil_div(w + 2, (uint32_t)kOutCols); }
+inline uint32_t loss_blocks_y(uint32_t h) { return ceil_div(h + 2, (uint32_t)kSegRows); }
+constexpr uint32_t kL1Blocks = 1024;
+
+}  // namespace
+}  // namespace brush
+
+using namespace brush;
+
+extern "C" int brush_loss_workspace_size(uint32_t w, uint32_t h, size_t *bytes) {
+    if (!bytes || w == 0 || h == 0) return BRUSH_ERR_INVALID_ARG;
+    const size_t plane = (size_t)(w + 2) * (h + 2);
+    const size_t nblk = std::max<size_t>((size_t)loss_blocks_x(w) * loss_blocks_y(h) * 3, kL1Blocks);
+    *bytes = align_up(9 * plane * sizeof(float), 256) + align_up(2 * nblk * sizeof(float), 256);
+    return BRUSH_OK;
+}
+
+extern "C" int brush_l1_ssim_loss(const float *pred, const float *gt, uint32_t w, uint32_t h, uint32_t gt_channels,
+                                  float ssim_weight, uint32_t ssim_window, float grad_scale, float *loss,
+                                  float *v_pred, void *workspace, size_t workspace_bytes, brush_stream_t stream) {
+    if (!pred || !gt || !loss || !v_pred || !workspace || w == 0 || h == 0) return BRUSH_ERR_INVALID_ARG;
+    if (gt_channels != 3 && gt_channels != 4) return BRUSH_ERR_INVALID_ARG;
+    if (ssim_weight > 0.0f && ssim_window != (uint32_t)kWin) return BRUSH_ERR_INVALID_ARG;
+    size_t need = 0;
+    brush_loss_workspace_size(w, h, &need);
+    if (workspace_bytes < need) return BRUSH_ERR_WORKSPACE_SMALL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t plane = (size_t)(w + 2) * (h + 2);
+    float *dmaps = static_cast<float *>(workspace);
+    float *partials = reinterpret_cast<float *>(static_cast<char *>(workspace) + align_up(9 * plane * sizeof(float), 256));
+    const float inv_l1 = 1.0f / ((float)w * (float)h * (float)gt_channels);
+    const float4 *pred4 = reinterpret_cast<const float4 *>(pred);
+    float4 *v4 = reinterpret_cast<float4 *>(v_pred);
+    if (!(ssim_weight > 0.0f)) {
+        const uint32_t npix = w * h, nblk = std::min(ceil_div(npix, 256u), kL1Blocks);
+        hipLaunchKernelGGL(k_l1_backward, dim3(nblk), dim3(256), 0, s, pred4, gt, gt_channels, npix, grad_scale * inv_l1,
+                           v4, partials);
+        hipLaunchKernelGGL(k_l1_finalize, dim3(1), dim3(64), 0, s, partials, nblk, inv_l1, loss);
+        BRUSH_HIP_CHECK(hipGetLastError());
+        return BRUSH_OK;
+    }
+    const Window win = make_window();
+    const float inv_ssim = 1.0f / (3.0f * (float)plane);
+    const dim3 gf(loss_blocks_x(w), loss_blocks_y(h)), gb(ceil_div(w, (uint32_t)kOutCols), ceil_div(h, (uint32_t)kSegRows));
+    hipLaunchKernelGGL(k_ssim_forward, gf, dim3(192), 0, s, pred, gt, gt_channels, w, h, win,
+                       -ssim_weight * inv_ssim * grad_scale, dmaps, partials);
+    hipLaunchKernelGGL(k_ssim_backward, gb, dim3(192), 0, s, pred, gt, gt_channels, w, h, win, dmaps,
+                       (1.0f - ssim_weight) * inv_l1 * grad_scale, v_pred, partials, gf.x * gf.y * 3, 1.0f - ssim_weight,
+                       ssim_weight, inv_l1, inv_ssim, loss);
+    BRUSH_HIP_CHECK(hipGetLastError());
+    return BRUSH_OK;
+}
+
+extern "C" int brush_adam_step(const BrushAdamConfig *cfg, uint32_t n, uint32_t sh_degree, float *means,
+                               float *log_scales, float *quats, float *raw_opac, float *sh, const float *v_means,
+                               const float *v_scales, const float *v_quats, const float *v_opac, const float *v_sh,
+                               float *moment1, float *moment2, brush_stream_t stream) {
+    if (!cfg || sh_degree > 4 || cfg->time == 0) return BRUSH_ERR_INVALID_ARG;
+    if (n == 0) return BRUSH_OK;
+    if (!means || !log_scales || !quats || !raw_opac || !sh || !v_means || !v_scales || !v_quats || !v_opac || !v_sh ||
+        !moment1 || !moment2)
+        return BRUSH_ERR_INVALID_ARG;
+    const uint32_t C = (sh_degree + 1) * (sh_degree + 1);
+    const size_t total = (size_t)n * (11 + 3 * C);
+    if (total / 256 > 0x7FFFFFFFull) return BRUSH_ERR_INVALID_ARG;
+    AdamArgs a;
+    a.lr[0] = cfg->lr_mean, a.lr[1] = cfg->lr_scale, a.lr[2] = cfg->lr_rotation, a.lr[3] = cfg->lr_opac;
+    a.lr[4] = cfg->lr_coeffs_dc;
+    a.sh_lerp = cfg->sh_rest_lerp, a.beta1 = cfg->beta1, a.beta2 = cfg->beta2, a.eps = cfg->epsilon;
+    a.bc1 = 1.0f - powf(cfg->beta1, (float)cfg->time);  // burn Adam: 1 - beta^time
+    a.bc2 = 1.0f - powf(cfg->beta2, (float)cfg->time);
+    a.n = n, a.ncoef = C, a.quat_vjp = cfg->rotation_grad_wrt_normalized;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = (n % 4 == 0) && aligned(means) && aligned(log_scales) && aligned(quats) && aligned(raw_opac) &&
+                     aligned(sh) && aligned(v_means) && aligned(v_scales) && aligned(v_quats) && aligned(v_opac) &&
+                     aligned(v_sh) && aligned(moment1) && aligned(moment2);
+    if (vec)
+        hipLaunchKernelGGL(k_adam<4>, dim3((uint32_t)((total / 4 + 255) / 256)), dim3(256), 0, s, a, means, log_scales,
+                           quats, raw_opac, sh, v_means, v_scales, v_quats, v_opac, v_sh, moment1, moment2, total);
+    else
+        hipLaunchKernelGGL(k_adam<1>, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, a, means, log_scales,
+                           quats, raw_opac, sh, v_means, v_scales, v_quats, v_opac, v_sh, moment1, moment2, total);
+    BRUSH_HIP_CHECK(hipGetLastError());
+    return BRUSH_OK;
+}
+
+extern "C" int brush_normalize_quats(const float *rotation, float *normalized, uint32_t n, brush_stream_t stream) {
+    if (n == 0) return BRUSH_OK;
+    if (!rotation || !normalized || (reinterpret_cast<uintptr_t>(rotation) & 15) || (reinterpret_cast<uintptr_t>(normalized) & 15))
+        return BRUSH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_normalize_quats, dim3(ceil_div(n, 256u)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4 *>(rotation), reinterpret_cast<float4 *>(normalized), n);
+    BRUSH_HIP_CHECK(hipGetLastError());
+    return BRUSH_OK;
+}
+
+extern "C" int brush_refine_stats(const BrushAux *h_aux, const float *v_xy, uint32_t n, uint32_t w, uint32_t h,
+                                  float *grad_2d_accum, float *xy_grad_counts, brush_stream_t stream) {
+    if (!h_aux || !h_aux->num_visible || !h_aux->global_from_compact_gid) return BRUSH_ERR_INVALID_ARG;
+    if (n == 0) return BRUSH_OK;
+    if (!v_xy || !grad_2d_accum || !xy_grad_counts) return BRUSH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_refine_stats, dim3(ceil_div(n, 256u)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       h_aux->num_visible, h_aux->global_from_compact_gid, reinterpret_cast<const float2 *>(v_xy), n,
+                       (float)w / 2.0f, (float)h / 2.0f, grad_2d_accum, xy_grad_counts);
+    BRUSH_HIP_CHECK(hipGetLastError());
+    return BRUSH_OK;
+}

@@ -161,6 +161,48 @@ int brush_expand_view_records(const float *records, uint32_t num_records, uint32
                               float *v_scales, float *v_quats, float *v_opac, float *v_sh,
                               brush_stream_t stream);
 
+/* ---- training iteration around the op (build extension) -------------------- */
+/* The reference's SplatTrainer::step (crates/brush-train/src/train.rs:211-393) wraps the op in
+ * Burn tensor ops: image loss, Adam, gradient statistics.  These entry points are the fused
+ * HIP equivalents, so the metric's train iters/s is not bounded by caller-side launches. */
+
+/* loss = mean|pred_cmp - gt| * (1 - ssim_weight) - SSIM(pred_rgb, gt_rgb) * ssim_weight when
+ * ssim_weight > 0, else the plain L1 mean (train.rs:243-268); SSIM as ssim.rs:42-101 (window 11,
+ * sigma 1.5, zero padding 6 so the SSIM map is (h+2)x(w+2), variances clamped at 0).
+ * pred: [h,w,4]; gt: [h,w,gt_channels], gt_channels 3 or 4 (4 compares alpha too, train.rs:248-252).
+ * Writes loss[0] (device) and v_pred [h,w,4] = grad_scale * d loss / d pred.  ssim_window must be 11. */
+int brush_loss_workspace_size(uint32_t w, uint32_t h, size_t *bytes);
+int brush_l1_ssim_loss(const float *pred, const float *gt, uint32_t w, uint32_t h, uint32_t gt_channels,
+                       float ssim_weight, uint32_t ssim_window, float grad_scale, float *loss, float *v_pred,
+                       void *workspace, size_t workspace_bytes, brush_stream_t stream);
+
+/* Hyper-parameters of one optimizer step: the five learning rates of train.rs:275-282, the lerp
+ * factor 1/lr_coeffs_sh_scale for SH coefficients >= 1 (train.rs:336-351), Adam betas/epsilon
+ * (AdamConfig::new().with_epsilon(1e-15), train.rs:184) and the 1-based step count. */
+typedef struct BrushAdamConfig {
+    float lr_mean, lr_scale, lr_rotation, lr_opac, lr_coeffs_dc, sh_rest_lerp;
+    float beta1, beta2, epsilon;
+    uint32_t time;
+    /* 1: `quats` holds the raw rotation parameter and v_quats is the gradient wrt rotation/|rotation|
+     * (what Splats::render feeds the op, gaussian_splats.rs:174-175); the chain rule through the
+     * normalisation is applied before the moment update.  0: v_quats is used as is. */
+    uint32_t rotation_grad_wrt_normalized;
+} BrushAdamConfig;
+/* One Adam step on all five parameter groups in one launch.  v_*: the gradient arrays of
+ * brush_render_backward; moment1 / moment2: N*(11+3C) floats each, owned by the caller, laid out
+ * [means 3N | log_scales 3N | quats 4N | raw_opac N | sh 3CN] and zero before the first step.
+ * Parameters are updated in place. */
+int brush_adam_step(const BrushAdamConfig *cfg, uint32_t n, uint32_t sh_degree, float *means, float *log_scales,
+                    float *quats, float *raw_opac, float *sh, const float *v_means, const float *v_scales,
+                    const float *v_quats, const float *v_opac, const float *v_sh, float *moment1,
+                    float *moment2, brush_stream_t stream);
+/* normalized[i] = rotation[i] / |rotation[i]| (gaussian_splats.rs:174-175); [N,4], 16-byte aligned. */
+int brush_normalize_quats(const float *rotation, float *normalized, uint32_t n, brush_stream_t stream);
+/* train.rs:284-316: grad_2d_accum[g] += |v_xy[g] * (w/2, h/2)|; xy_grad_counts[g] += 1 for every
+ * visible splat g of this view (both [N] f32). */
+int brush_refine_stats(const BrushAux *h_aux, const float *v_xy, uint32_t n, uint32_t w, uint32_t h,
+                       float *grad_2d_accum, float *xy_grad_counts, brush_stream_t stream);
+
 /* ---- opt-in stage timing ---------------------------------------------------------------- */
 /* Counterpart of the reference's tracing spans + sync-span layer (render.rs:69-267,474-577;
  * crates/sync-span/src/lib.rs:12-49): when a profiler is attached to the calling host thread,

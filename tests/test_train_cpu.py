@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 def test_separable_ssim_equals_reference_window():
     """ssim.rs:36-101: the 2-D window is outer(g, g); the harness applies it as two 1-D passes."""
-    from brush_amd.train import Ssim
+    from tests.torch_trainer import Ssim
 
     torch.manual_seed(0)
     a, b = torch.rand(1, 37, 53, 3), torch.rand(1, 37, 53, 3)

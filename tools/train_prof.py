@@ -1,0 +1,24 @@
+"""Runs a few full training iterations on the S1 workload (for rocprofv3 --kernel-trace --stats)."""
+import sys, time
+import torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import helpers as H
+import brush_amd
+dev = torch.device("cuda:0")
+n, w, h, deg = 1 << 20, 1920, 1080, 3
+cloud = H.synthetic_cloud(n, deg, seed=4)
+p = {k: torch.from_numpy(v).to(dev) for k, v in cloud.items()}
+c = H.reference_test_camera(w, h)
+cam = brush_amd.Camera(c["position"], c["rotation_xyzw"], c["fov_x"], c["fov_y"], c["center_uv"])
+splats = brush_amd.Splats(p["means"], p["sh"], p["quats"], p["raw_opac"], p["log_scales"])
+trainer = brush_amd.SplatTrainer(splats, brush_amd.TrainConfig(warmup_steps=0))
+gt = torch.rand((h, w, 3), dtype=torch.float32, device=dev)
+for _ in range(3):
+    trainer.step(splats, cam, gt)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+for _ in range(K):
+    trainer.step(splats, cam, gt)
+torch.cuda.synchronize()
+print("ms/iter", (time.perf_counter() - t0) / K * 1e3)
