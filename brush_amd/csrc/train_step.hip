@@ -45,10 +45,11 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 }
 
 // LDS traffic inside one wave is in order; this only stops the compiler from moving accesses.
+// A fence would also wait for the prefetched global loads, so this is a pure compiler barrier.
 __device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
 // Both loss kernels march a wave down a strip of 64 columns for one colour channel (wave = channel,
@@ -78,22 +79,36 @@ __global__ __launch_bounds__(192) void k_ssim_forward(const float *__restrict__ 
     const size_t plane = (size_t)W2 * H2;
     float hq[kWin][5];
     float msum = 0.0f, l1 = 0.0f;
+    // marched row r -> (a, b, alpha pair) of the lane's column, zero outside the image.  Loads are
+    // unconditional (clamped address + select) and issued three rows ahead of their use, so the
+    // vmcnt waits the compiler places leave the younger rows in flight.
+    const bool alpha_on = ch == 0 && gt_channels == 4;
+    const int ixc = min(max(ix, 0), (int)w - 1);
+    struct Row {
+        float a, b, pa, ga;
+    };
+    auto fetch = [&](int r) {
+        const int iy = oy0 - kPad + r;
+        const bool ok = col_ok && iy >= 0 && iy < (int)h;
+        const size_t px = (size_t)min(max(iy, 0), (int)h - 1) * w + ixc;
+        Row v;
+        v.a = pred[px * 4 + ch];
+        v.b = gt[px * gt_channels + ch];
+        v.pa = pred[px * 4 + (alpha_on ? 3 : ch)];
+        v.ga = gt[px * gt_channels + (alpha_on ? 3 : ch)];
+        v.a = ok ? v.a : 0.0f, v.b = ok ? v.b : 0.0f;
+        v.pa = ok && alpha_on ? v.pa : 0.0f, v.ga = ok && alpha_on ? v.ga : 0.0f;
+        return v;
+    };
+    Row c0 = fetch(0), c1 = fetch(1), c2 = fetch(2);
     for (int r0 = 0; r0 < kSegRows + kWin - 1; r0 += kWin) {
 #pragma unroll
         for (int j = 0; j < kWin; j++) {
             const int r = r0 + j;
-            const int iy = oy0 - kPad + r;
-            float a = 0.0f, b = 0.0f;
-            if (col_ok && iy >= 0 && iy < (int)h) {
-                const size_t px = (size_t)iy * w + ix;
-                a = pred[px * 4 + ch];
-                b = gt[px * gt_channels + ch];
-                if (own_col && r >= kPad - 1 && r < kPad - 1 + kSegRows) {
-                    l1 += fabsf(a - b);
-                    if (ch == 0 && gt_channels == 4) l1 += fabsf(pred[px * 4 + 3] - gt[px * 4 + 3]);
-                }
-            }
-            ra[l] = a, rb[l] = b;
+            ra[l] = c0.a, rb[l] = c0.b;
+            if (own_col && r >= kPad - 1 && r < kPad - 1 + kSegRows) l1 += fabsf(c0.a - c0.b) + fabsf(c0.pa - c0.ga);
+            c0 = c1, c1 = c2;
+            c2 = fetch(r + 3);
             wave_lds_sync();
             float sa = 0.f, sb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
 #pragma unroll
@@ -161,17 +176,34 @@ __global__ __launch_bounds__(192) void k_ssim_backward(const float *__restrict__
     const float *d0 = dmaps + (0 * 3 + ch) * plane, *d1 = dmaps + (1 * 3 + ch) * plane, *d2 = dmaps + (2 * 3 + ch) * plane;
     auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };
     float hq[kWin][3];
+    // marched row r: the three map values of the lane's column and (a, b, alpha pair) of the pixel the
+    // iteration will emit (row py0 + r - 10); unconditional loads three rows ahead, as in the forward.
+    const bool alpha_on = gt_channels == 4;
+    const int oxc = min(max(ox, 0), W2 - 1), pxc = min(px, (int)w - 1);
+    struct Row {
+        float x0, x1, x2, a, b, pa, ga;
+    };
+    auto fetch = [&](int r) {
+        const int oy = py0 - kOff + r;
+        const bool ok = col_ok && oy >= 0 && oy < H2;
+        const size_t o = (size_t)min(max(oy, 0), H2 - 1) * W2 + oxc;
+        const size_t p = (size_t)min(max(py0 + r - (kWin - 1), 0), (int)h - 1) * w + pxc;
+        Row v;
+        v.x0 = d0[o], v.x1 = d1[o], v.x2 = d2[o];
+        v.a = pred[p * 4 + ch], v.b = gt[p * gt_channels + ch];
+        v.pa = pred[p * 4 + 3], v.ga = gt[p * gt_channels + (alpha_on ? 3 : 0)];
+        v.x0 = ok ? v.x0 : 0.0f, v.x1 = ok ? v.x1 : 0.0f, v.x2 = ok ? v.x2 : 0.0f;
+        return v;
+    };
+    Row c0 = fetch(0), c1 = fetch(1), c2 = fetch(2);
     for (int r0 = 0; r0 < kSegRows + kWin - 1; r0 += kWin) {
 #pragma unroll
         for (int j = 0; j < kWin; j++) {
             const int r = r0 + j;
-            const int oy = py0 - kOff + r;
-            float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f;
-            if (col_ok && oy >= 0 && oy < H2) {
-                const size_t o = (size_t)oy * W2 + ox;
-                x0 = d0[o], x1 = d1[o], x2 = d2[o];
-            }
-            rows[ch][0][l] = x0, rows[ch][1][l] = x1, rows[ch][2][l] = x2;
+            rows[ch][0][l] = c0.x0, rows[ch][1][l] = c0.x1, rows[ch][2][l] = c0.x2;
+            const float a = c0.a, b = c0.b, pa = c0.pa, ga = c0.ga;
+            c0 = c1, c1 = c2;
+            c2 = fetch(r + 3);
             wave_lds_sync();
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -191,10 +223,9 @@ __global__ __launch_bounds__(192) void k_ssim_backward(const float *__restrict__
                     for (int q = 0; q < 3; q++) t[q] += win.g[k] * hq[(j + 1 + k) % kWin][q];
                 }
                 const size_t p = (size_t)py * w + px;
-                const float a = pred[p * 4 + ch], b = gt[p * gt_channels + ch];
                 v_pred[p * 4 + ch] = t[0] + 2.0f * a * t[1] + b * t[2] + l1_coef * sgn(a - b);
                 if (ch == 0)  // alpha: compared only when the target has alpha (train.rs:248-252)
-                    v_pred[p * 4 + 3] = gt_channels == 4 ? l1_coef * sgn(pred[p * 4 + 3] - gt[p * 4 + 3]) : 0.0f;
+                    v_pred[p * 4 + 3] = alpha_on ? l1_coef * sgn(pa - ga) : 0.0f;
             }
         }
     }
