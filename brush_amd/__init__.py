@@ -19,5 +19,6 @@ from .sort import radix_argsort  # noqa: F401
 from .prefix_sum import prefix_sum  # noqa: F401
 from .gaussian_splats import Splats  # noqa: F401
 from .train import SplatTrainer, TrainConfig  # noqa: F401
+from . import dataset  # noqa: F401
 
 __version__ = "0.1.0"
