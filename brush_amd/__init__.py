@@ -14,7 +14,8 @@ gfx950).  There is no CPU fallback: importing the compute entry points without t
 library raises.
 """
 from .camera import Camera, fov_to_focal, focal_to_fov  # noqa: F401
-from .render import RenderAux, render_splats, sh_coeffs_for_degree, sh_degree_from_coeffs  # noqa: F401
+from .render import (RenderAux, render_rgba8, render_splats, rgba8_row_pitch, sh_coeffs_for_degree,  # noqa: F401
+                     sh_degree_from_coeffs)
 from .sort import radix_argsort  # noqa: F401
 from .prefix_sum import prefix_sum  # noqa: F401
 from .gaussian_splats import Splats  # noqa: F401

@@ -81,6 +81,10 @@ _SYMBOLS = [
     ("brush_render_forward", C.c_int,
      [C.POINTER(BrushUniforms), _P, _P, _P, _P, _P, C.c_uint32, C.c_int, _P, C.POINTER(BrushAux), _P,
       C.c_size_t, _P]),
+    ("brush_rgba8_row_pitch", C.c_uint32, [C.c_uint32]),
+    ("brush_render_forward_rgba8", C.c_int,
+     [C.POINTER(BrushUniforms), _P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(BrushAux), _P,
+      C.c_size_t, _P]),
     ("brush_bwd_workspace_size", C.c_int,
      [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
     ("brush_render_backward", C.c_int,

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32
                                                      const uint32_t *__restrict__ tile_bins,
                                                      const float *__restrict__ projected,
                                                      void *__restrict__ out_img,
-                                                     uint32_t *__restrict__ final_index) {
+                                                     uint32_t *__restrict__ final_index, uint32_t u32_pitch) {
     __shared__ SplatLds lds_all[kTilesPerBlock];
     using M = LaneMap<PIX>;
     constexpr uint32_t kPix = PIX, kPairs = M::kPairs;
@@ -188,7 +188,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32
                     const uint32_t g8 = (uint32_t)fminf(fmaxf(gj * 255.0f, 0.0f), 255.0f);
                     const uint32_t b8 = (uint32_t)fminf(fmaxf(bj * 255.0f, 0.0f), 255.0f);
                     const uint32_t a8 = (uint32_t)fminf(fmaxf(al * 255.0f, 0.0f), 255.0f);
-                    static_cast<uint32_t *>(out_img)[pix] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+                    // rows `u32_pitch` pixels apart (the viewer's 256-byte row pitch, burn_texture.rs:17-26)
+                    static_cast<uint32_t *>(out_img)[(size_t)(px0 + j) + (size_t)py * u32_pitch] =
+                        r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
                 } else {
                     static_cast<float4 *>(out_img)[pix] = make_float4(rj, gj, bj, al);
                     final_index[pix] = fin[j];
@@ -423,8 +425,8 @@ constexpr uint32_t kMinTilesForOneWave = 6144;
 
 hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                             const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
-                            const float *projected, int raster_u32, void *out_img, uint32_t *final_index,
-                            hipStream_t s) {
+                            const float *projected, int raster_u32, uint32_t u32_pitch, void *out_img,
+                            uint32_t *final_index, hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
     const bool wide = tiles >= kMinTilesForOneWave;
@@ -432,7 +434,7 @@ hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
     const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
 #define BRUSH_RASTER(U32, PIX)                                                                              \
     hipLaunchKernelGGL((k_rasterize<U32, PIX>), grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, \
-                       tile_bins, projected, out_img, final_index)
+                       tile_bins, projected, out_img, final_index, u32_pitch)
     if (raster_u32) {
         if (wide) BRUSH_RASTER(true, 4); else BRUSH_RASTER(true, 2);
     } else {

@@ -159,10 +159,10 @@ extern "C" int brush_bwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint
     return BRUSH_OK;
 }
 
-extern "C" int brush_render_forward(const BrushUniforms *h_uniforms, const float *means, const float *log_scales,
-                                    const float *quats, const float *sh_coeffs, const float *raw_opacity,
-                                    uint32_t n, int raster_u32, void *out_img, const BrushAux *h_aux,
-                                    void *workspace, size_t workspace_bytes, brush_stream_t stream) {
+static int render_forward_impl(const BrushUniforms *h_uniforms, const float *means, const float *log_scales,
+                               const float *quats, const float *sh_coeffs, const float *raw_opacity, uint32_t n,
+                               int raster_u32, uint32_t u32_pitch, void *out_img, const BrushAux *h_aux,
+                               void *workspace, size_t workspace_bytes, brush_stream_t stream) {
     if (!uniforms_ok(h_uniforms) || !aux_ok(h_aux, !raster_u32) || !out_img || !workspace)
         return BRUSH_ERR_INVALID_ARG;
     if (n > 0 && (!means || !log_scales || !quats || !sh_coeffs || !raw_opacity)) return BRUSH_ERR_INVALID_ARG;
@@ -216,10 +216,31 @@ extern "C" int brush_render_forward(const BrushUniforms *h_uniforms, const float
     mark_fwd(s, 1 + BRUSH_STAGE_TILE_BINS);
     // Rasterize (render.rs:267-307)
     BRUSH_HIP_CHECK(launch_rasterize(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
-                                     aux.projected_splats, raster_u32, out_img, aux.final_index, s));
+                                     aux.projected_splats, raster_u32, u32_pitch ? u32_pitch : w, out_img,
+                                     aux.final_index, s));
     mark_fwd(s, 1 + BRUSH_STAGE_RASTERIZE);
     return BRUSH_OK;
 }
+
+extern "C" int brush_render_forward(const BrushUniforms *h_uniforms, const float *means, const float *log_scales,
+                                    const float *quats, const float *sh_coeffs, const float *raw_opacity,
+                                    uint32_t n, int raster_u32, void *out_img, const BrushAux *h_aux,
+                                    void *workspace, size_t workspace_bytes, brush_stream_t stream) {
+    return render_forward_impl(h_uniforms, means, log_scales, quats, sh_coeffs, raw_opacity, n, raster_u32, 0, out_img,
+                               h_aux, workspace, workspace_bytes, stream);
+}
+
+extern "C" int brush_render_forward_rgba8(const BrushUniforms *h_uniforms, const float *means,
+                                          const float *log_scales, const float *quats, const float *sh_coeffs,
+                                          const float *raw_opacity, uint32_t n, uint32_t *out_img,
+                                          uint32_t row_pitch_pixels, const BrushAux *h_aux, void *workspace,
+                                          size_t workspace_bytes, brush_stream_t stream) {
+    if (!h_uniforms || row_pitch_pixels < h_uniforms->img_size[0]) return BRUSH_ERR_INVALID_ARG;
+    return render_forward_impl(h_uniforms, means, log_scales, quats, sh_coeffs, raw_opacity, n, 1, row_pitch_pixels,
+                               out_img, h_aux, workspace, workspace_bytes, stream);
+}
+
+extern "C" uint32_t brush_rgba8_row_pitch(uint32_t width) { return (width + 63u) / 64u * 64u; }
 
 extern "C" int brush_render_backward(const BrushUniforms *h_uniforms, const BrushAux *h_aux, const float *means,
                                      const float *log_scales, const float *quats, const float *raw_opacity,

@@ -121,7 +121,7 @@ def _check_inputs(means, xy_dummy, log_scales, quats, sh_coeffs, raw_opacity):
 
 
 def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, raw_opacity, render_u32: bool,
-                  max_intersects: Optional[int]):
+                  max_intersects: Optional[int], row_pitch: Optional[int] = None):
     l = _lib.lib()
     n = means.shape[0]
     w, h = int(img_size[0]), int(img_size[1])
@@ -147,7 +147,12 @@ def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, ra
         overflow=_empty((1,), i32, dev),
         max_intersects=cap,
     )
-    out = _empty((h, w, 1), i32, dev) if render_u32 else _empty((h, w, 4), torch.float32, dev)
+    if row_pitch is not None:
+        if not render_u32 or row_pitch < w:
+            raise ValueError("row_pitch needs render_u32_buffer=True and row_pitch >= width")
+        out = torch.zeros((h, int(row_pitch), 1), dtype=i32, device=dev)  # padding columns stay 0 (burn_texture.rs:21-24)
+    else:
+        out = _empty((h, w, 1), i32, dev) if render_u32 else _empty((h, w, 4), torch.float32, dev)
     nbytes = C.c_size_t()
     _lib.check(l.brush_fwd_workspace_size(n, w, h, sh_degree, cap, C.byref(nbytes)), "brush_fwd_workspace_size")
     ws = _empty((max(nbytes.value, 1),), torch.uint8, dev)
@@ -156,10 +161,16 @@ def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, ra
     s = aux._as_struct()
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(l.brush_render_forward(C.byref(u), means.data_ptr(), log_scales.data_ptr(), quats.data_ptr(),
-                                          sh_coeffs.data_ptr(), raw_opacity.data_ptr(), n, 1 if render_u32 else 0,
-                                          out.data_ptr(), C.byref(s), ws.data_ptr(), nbytes.value, stream),
-                   "brush_render_forward")
+        if row_pitch is not None:
+            _lib.check(l.brush_render_forward_rgba8(C.byref(u), means.data_ptr(), log_scales.data_ptr(),
+                                                    quats.data_ptr(), sh_coeffs.data_ptr(), raw_opacity.data_ptr(), n,
+                                                    out.data_ptr(), int(row_pitch), C.byref(s), ws.data_ptr(),
+                                                    nbytes.value, stream), "brush_render_forward_rgba8")
+        else:
+            _lib.check(l.brush_render_forward(C.byref(u), means.data_ptr(), log_scales.data_ptr(), quats.data_ptr(),
+                                              sh_coeffs.data_ptr(), raw_opacity.data_ptr(), n, 1 if render_u32 else 0,
+                                              out.data_ptr(), C.byref(s), ws.data_ptr(), nbytes.value, stream),
+                       "brush_render_forward")
     return out, aux, u
 
 
@@ -259,6 +270,24 @@ def render_splats(cam: Camera, img_size, means: torch.Tensor, xy_grad_dummy: Opt
     holder = {"cam": cam, "img_size": img_size, "max_intersects": max_intersects}
     out = _RenderSplatsFn.apply(means, xy_grad_dummy, log_scales, quats, sh_coeffs, raw_opacity, holder)
     return out, holder["aux"]
+
+
+def rgba8_row_pitch(width: int) -> int:
+    """Pixels per row the viewer's texture upload wants: ceil(width/64)*64 (burn_texture.rs:17-26)."""
+    return int(_lib.lib().brush_rgba8_row_pitch(int(width)))
+
+
+def render_rgba8(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, raw_opacity,
+                 row_pitch: Optional[int] = None, max_intersects: Optional[int] = None):
+    """Forward-only display path: packed RGBA8 with rows `row_pitch` pixels apart (default
+    rgba8_row_pitch(width)), i.e. the padded tensor burn_texture.rs:17-26 builds with a zero-fill
+    and a slice_assign, written by the rasterizer directly.  Returns (int32 [h, row_pitch, 1], aux)."""
+    _check_inputs(means, None, log_scales, quats, sh_coeffs, raw_opacity)
+    pitch = rgba8_row_pitch(img_size[0]) if row_pitch is None else int(row_pitch)
+    with torch.no_grad():
+        out, aux, _ = _forward_impl(cam, img_size, means, log_scales, quats, sh_coeffs, raw_opacity, True,
+                                    max_intersects, row_pitch=pitch)
+    return out, aux
 
 
 def uniforms_to_numpy(aux: RenderAux) -> dict:

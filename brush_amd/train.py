@@ -1,7 +1,7 @@
 """Training iteration around the op — what the metric's train iters/s measures.
 
-Mirror of the reference's `SplatTrainer::step` (crates/brush-train/src/train.rs:211-393) minus
-refinement/densification: render, loss = L1*(1-w) - SSIM*w (train.rs:243-268, ssim.rs:42-101),
+Mirror of the reference's `SplatTrainer::step` (crates/brush-train/src/train.rs:211-393) and
+`refine_splats` (train.rs:395-579; periodic, plain torch tensor ops): render, loss = L1*(1-w) - SSIM*w (train.rs:243-268, ssim.rs:42-101),
 backward, screen-space gradient statistics (train.rs:284-316), Adam with eps 1e-15 on the five
 parameter groups and the higher-order-SH learning-rate lerp (train.rs:318-359).
 
@@ -12,6 +12,7 @@ straight on the op's forward/backward, so one iteration is ≈40 kernel launches
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass
 from typing import Callable, Optional
 
@@ -38,6 +39,39 @@ class TrainConfig:
     lr_opac: float = 0.05
     lr_scale: float = 0.01
     lr_rotation: float = 0.002
+    # refinement (train.rs:25-53)
+    refine_every: int = 100
+    max_refine_step: int = 15000
+    reset_alpha_value: float = 0.004
+    cull_alpha_thresh: float = 0.005
+    cull_scale_thresh: float = 5.0
+    reset_alpha_every_refine: int = 30
+    densify_grad_thresh: float = 0.0002
+    densify_size_thresh: float = 0.005
+    seed: int = 42
+
+
+@dataclass
+class RefineStats:
+    """train.rs:95-101"""
+    num_split: int
+    num_cloned: int
+    num_transparent_pruned: int
+    num_scale_pruned: int
+
+
+def quaternion_vec_multiply(q: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """train.rs:140-177, term by term (quaternions as (w, x, y, z))."""
+    qw, qx, qy, qz = q[:, 0:1], q[:, 1:2], q[:, 2:3], q[:, 3:4]
+    vx, vy, vz = v[:, 0:1], v[:, 1:2], v[:, 2:3]
+    t1 = qw * vx + qy * vz - qz * vy
+    t2 = qw * vy - qx * vz + qz * vx
+    t3 = qw * vz + qx * vy - qy * vx
+    t4 = qx * vx + qy * vy + qz * vz
+    rx = vx + (qw * t1 + qx * t4 - qy * t3 + qz * t2) * 2.0
+    ry = vy + (qw * t2 - qx * t3 + qy * t4 + qz * t1) * 2.0
+    rz = vz + (qw * t3 + qx * t2 - qy * t1 + qz * t4) * 2.0
+    return torch.cat([rx, ry, rz], dim=1)
 
 
 def l1_ssim_loss(pred: torch.Tensor, gt: torch.Tensor, ssim_weight: float, window: int = 11,
@@ -75,6 +109,77 @@ class SplatTrainer:
         # Adam moments of the five groups, [means|log_scales|quats|raw_opac|sh] (AdamConfig of train.rs:184)
         self.moment1 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
         self.moment2 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
+        self.opt_time = 0  # Adam's per-parameter step count (reset with the optimizer at refinement)
+        self.last_refine: Optional[RefineStats] = None
+        self.rng = torch.Generator(device=dev)
+        self.rng.manual_seed(self.config.seed)
+
+    def _reset(self, n: int, ncoef: int, dev):
+        """reset_stats + `self.optim = self.opt_config.init()` (train.rs:201-204,559-563)."""
+        self.grad_2d_accum = torch.zeros(n, device=dev)
+        self.xy_grad_counts = torch.zeros(n, device=dev)
+        self.moment1 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
+        self.moment2 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
+        self.opt_time = 0
+
+    @torch.no_grad()
+    def refine_splats(self, splats: Splats, pre_step: dict) -> RefineStats:
+        """train.rs:395-579.  `splats` holds the post-step parameters and is rebuilt in place
+        (clone / split / prune / opacity reset); `pre_step` holds the parameters before the optimizer
+        step (clones and split positions are taken from those).  As in the reference, the shrunken
+        scale and the re-sampled mean of a split *source* are computed on temporaries that are dropped
+        (train.rs:402,500-526 vs 528): only the appended splats change."""
+        c = self.config
+        dev = splats.means.device
+        post = {"means": splats.means.detach(), "rotation": splats.rotation.detach(), "sh": splats.sh_coeffs.detach(),
+                "opac": splats.raw_opacity.detach(), "scales": splats.log_scales.detach()}
+        grads = self.grad_2d_accum / self.xy_grad_counts.clamp_min(1.0)
+        big_grad = grads >= c.densify_grad_thresh
+        small = post["scales"].exp().max(dim=1).values < c.densify_size_thresh
+        app = {k: [] for k in post}
+        clone_inds = torch.nonzero(small & big_grad).squeeze(1)
+        if clone_inds.numel() > 0:
+            for k in post:
+                app[k].append(pre_step[k][clone_inds])
+        split_inds = torch.nonzero(~small & big_grad).squeeze(1)
+        ns = int(split_inds.numel())
+        if ns > 0:
+            cur_rots = post["rotation"][split_inds]
+            cur_scale = post["scales"][split_inds].exp()
+            app["rotation"].append(cur_rots)
+            app["sh"].append(post["sh"][split_inds])
+            app["opac"].append(post["opac"][split_inds])
+            app["scales"].append((cur_scale / 1.6).log())
+            cur_means = pre_step["means"][split_inds]
+            # first sample: the source's re-sampled mean, dropped by the reference (kept for the RNG stream)
+            torch.randn((ns, 3), generator=self.rng, device=dev)
+            samples_new = quaternion_vec_multiply(cur_rots, torch.randn((ns, 3), generator=self.rng, device=dev) * 0.5
+                                                  * cur_scale)
+            app["means"].append(cur_means + samples_new)
+        new = {k: (torch.cat([post[k]] + app[k], 0) if app[k] else post[k]) for k in post}
+        start = new["means"].shape[0]
+
+        def prune(mask):
+            keep = torch.nonzero(~mask).squeeze(1)
+            if keep.numel() < mask.numel():
+                for k in new:
+                    new[k] = new[k][keep]
+
+        prune(torch.sigmoid(new["opac"]) < c.cull_alpha_thresh)
+        alpha_pruned = start - new["means"].shape[0]
+        prune(new["scales"].exp().max(dim=1).values > c.cull_scale_thresh)
+        scale_pruned = start - new["means"].shape[0]  # cumulative, as train.rs:551
+        if (self.iter // c.refine_every) % c.reset_alpha_every_refine == 0:
+            new["opac"] = torch.zeros_like(new["opac"]) + math.log(c.reset_alpha_value / (1.0 - c.reset_alpha_value))
+        splats.means = torch.nn.Parameter(new["means"].contiguous())
+        splats.rotation = torch.nn.Parameter(new["rotation"].contiguous())
+        splats.sh_coeffs = torch.nn.Parameter(new["sh"].contiguous())
+        splats.raw_opacity = torch.nn.Parameter(new["opac"].contiguous())
+        splats.log_scales = torch.nn.Parameter(new["scales"].contiguous())
+        n = splats.means.shape[0]
+        splats.xys_dummy = torch.zeros((n, 2), dtype=torch.float32, device=dev, requires_grad=True)
+        self._reset(n, int(splats.sh_coeffs.shape[1]), dev)
+        return RefineStats(ns, int(clone_inds.numel()), alpha_pruned, scale_pruned)
 
     def _lr_mean(self, scene_extent: float) -> float:
         c = self.config
@@ -91,7 +196,7 @@ class SplatTrainer:
         h, w = int(gt_image.shape[0]), int(gt_image.shape[1])
         n, ncoef = splats.num_splats(), int(splats.sh_coeffs.shape[1])
         if self.moment1.numel() != n * (11 + 3 * ncoef):
-            raise ValueError("the number of splats changed: build a new SplatTrainer (refinement is not part of step)")
+            raise ValueError("the number of splats changed outside refine_splats: build a new SplatTrainer")
         means, log_scales, quats = splats.means.detach(), splats.log_scales.detach(), splats.rotation.detach()
         sh, raw_opac = splats.sh_coeffs.detach(), splats.raw_opacity.detach()
         for t in (means, log_scales, quats, sh, raw_opac):
@@ -107,6 +212,11 @@ class SplatTrainer:
         if grad_sync is not None:  # view-sharded data parallelism: sum the per-view gradients
             grad_sync(block, aux)
 
+        do_refine = self.iter < c.max_refine_step and self.iter >= c.warmup_steps and self.iter % c.refine_every == 1
+        pre_step = None
+        if do_refine:  # refinement clones / splits the parameters *before* the optimizer step (train.rs:361-372)
+            pre_step = {"means": means.clone(), "rotation": quats.clone(), "sh": sh.clone(), "opac": raw_opac.clone(),
+                        "scales": log_scales.clone()}
         with torch.cuda.device(means.device):
             if self.iter > c.warmup_steps:  # housekeeping, train.rs:284-316
                 v_xy = grads["v_xy"]
@@ -121,7 +231,7 @@ class SplatTrainer:
                     _lib.check(l.brush_refine_stats(C.byref(s), v_xy.data_ptr(), n, w, h, self.grad_2d_accum.data_ptr(),
                                                     self.xy_grad_counts.data_ptr(), stream), "brush_refine_stats")
             cfg = _lib.BrushAdamConfig(self._lr_mean(scene_extent), c.lr_scale, c.lr_rotation, c.lr_opac,
-                                       c.lr_coeffs_dc, 1.0 / c.lr_coeffs_sh_scale, 0.9, 0.999, 1e-15, self.iter + 1, 1)
+                                       c.lr_coeffs_dc, 1.0 / c.lr_coeffs_sh_scale, 0.9, 0.999, 1e-15, self.opt_time + 1, 1)
             _lib.check(l.brush_adam_step(C.byref(cfg), n, R.sh_degree_from_coeffs(ncoef), means.data_ptr(),
                                          log_scales.data_ptr(), quats.data_ptr(), raw_opac.data_ptr(), sh.data_ptr(),
                                          grads["v_means"].data_ptr(), grads["v_scales"].data_ptr(),
@@ -129,5 +239,7 @@ class SplatTrainer:
                                          grads["v_sh"].data_ptr(), self.moment1.data_ptr(), self.moment2.data_ptr(),
                                          stream),
                        "brush_adam_step")
+        self.opt_time += 1
+        self.last_refine = self.refine_splats(splats, pre_step) if do_refine else None
         self.iter += 1
         return loss, pred, aux

@@ -124,6 +124,19 @@ int brush_render_forward(const BrushUniforms *h_uniforms, const float *means,
                          const BrushAux *h_aux, void *workspace, size_t workspace_bytes,
                          brush_stream_t stream);
 
+/* Forward-only display path: packed RGBA8 (rasterize.wgsl:106-109) written
+ * with rows `row_pitch_pixels` pixels apart, so the viewer's texture upload needs no padding
+ * copy.  The reference pads the [h,w] u32 image into a zero [h, ceil(w/64)*64] tensor because
+ * WebGPU wants bytes_per_row % 256 == 0 (crates/brush-ui/src/burn_texture.rs:17-26);
+ * brush_rgba8_row_pitch(w) returns that pitch.  out_img: [h * row_pitch_pixels] u32; columns
+ * >= w of each row are left untouched.  aux.final_index may be NULL (not written, as in the
+ * reference's RASTER_U32 variant).  Otherwise identical to brush_render_forward(raster_u32=1). */
+uint32_t brush_rgba8_row_pitch(uint32_t width);
+int brush_render_forward_rgba8(const BrushUniforms *uniforms, const float *means, const float *log_scales,
+                               const float *quats, const float *sh_coeffs, const float *raw_opacity,
+                               uint32_t n, uint32_t *out_img, uint32_t row_pitch_pixels, const BrushAux *aux,
+                               void *workspace, size_t workspace_bytes, brush_stream_t stream);
+
 /* ---- render backward ------------------------------------------------------------------ */
 int brush_bwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
                              size_t *bytes);

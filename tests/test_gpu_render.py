@@ -464,6 +464,32 @@ def test_degenerate_parameters_stay_in_bounds(dev):
     assert bool(torch.isfinite(clean).all())
 
 
+def test_rgba8_row_pitch_matches_padded_u32(dev):
+    """the pitched RGBA8 output equals the reference's padding of the packed image
+    into a zero [h, ceil(w/64)*64] tensor (burn_texture.rs:17-26), bit for bit."""
+    import torch
+
+    import brush_amd
+
+    for (w, h) in ((123, 82), (128, 40), (1000, 37)):
+        cloud = H.synthetic_cloud(3000, 1, seed=21, mean_mult=0.002)
+        p = {k: _t(v, dev) for k, v in cloud.items()}
+        cam = _camera(w, h)
+        tight, _ = brush_amd.render_splats(cam, (w, h), p["means"], None, p["log_scales"], p["quats"], p["sh"],
+                                           p["raw_opac"], render_u32_buffer=True)
+        pitch = brush_amd.rgba8_row_pitch(w)
+        assert pitch % 64 == 0 and 0 <= pitch - w < 64
+        padded, aux = brush_amd.render_rgba8(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"])
+        assert tuple(padded.shape) == (h, pitch, 1)
+        want = torch.zeros((h, pitch, 1), dtype=torch.int32, device=dev)
+        want[:, :w] = tight
+        assert torch.equal(padded, want)
+        assert int(tight.abs().max()) != 0 and aux.read_num_visible() > 0
+    with pytest.raises(ValueError):
+        brush_amd.render._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"], True, None,
+                                       row_pitch=w - 1)
+
+
 def test_compact_gradient_records_round_trip(dev):
     """brush_amd.dist: the 60-byte records of the visible splats reproduce the op's dense gradient
     block (the multi-GPU exchange all-gathers these instead of all-reducing 52+12C bytes/splat)."""

@@ -186,7 +186,7 @@ def test_hip_trainer_tracks_torch_trainer(dev):
     torch.manual_seed(3)
     gt = torch.rand((h, w, 3), device=dev)
     a, b = mk(), mk()
-    cfg = brush_amd.TrainConfig(warmup_steps=0)
+    cfg = brush_amd.TrainConfig(warmup_steps=0, max_refine_step=0)  # the torch restatement has no refinement
     ta, tb = brush_amd.SplatTrainer(a, cfg), TorchSplatTrainer(b, cfg)
     for i in range(3):
         la, _, _ = ta.step(a, cam, gt)
@@ -202,3 +202,93 @@ def test_hip_trainer_tracks_torch_trainer(dev):
         assert float((d > 0.05 * lr).float().mean()) < 0.02, name  # and that is rare
     assert torch.equal(ta.xy_grad_counts, tb.xy_grad_counts)
     assert float((ta.grad_2d_accum - tb.grad_2d_accum).abs().max()) <= 1e-3 * (1e-9 + float(tb.grad_2d_accum.abs().max()))
+
+
+def test_refine_splats_follows_reference_rules(dev):
+    """train.rs:395-579 on a hand-built state: clones come from the pre-step parameters, splits append
+    one down-scaled splat at a sampled offset (the source is left as is), pruning by opacity then by
+    scale with cumulative counts, opacity reset on refine step 0, statistics and Adam state reset."""
+    import torch
+
+    import brush_amd
+    from brush_amd.train import quaternion_vec_multiply
+
+    n, ncoef = 8, 4
+    g = torch.Generator().manual_seed(0)
+    means = torch.randn((n, 3), generator=g)
+    quats = torch.nn.functional.normalize(torch.randn((n, 4), generator=g), dim=1)
+    sh = torch.randn((n, ncoef, 3), generator=g)
+    # scales: splats 0-3 small (< 0.005), 4-7 large; splat 7 huge (> cull_scale_thresh 5.0)
+    log_scales = torch.log(torch.tensor([[0.001] * 3] * 4 + [[0.1, 0.2, 0.3]] * 3 + [[6.0, 0.1, 0.1]]))
+    raw_opac = torch.tensor([2.0, 2.0, -7.0, 2.0, 2.0, 2.0, 2.0, 2.0])  # splat 2 nearly transparent
+    splats = brush_amd.Splats(means.to(dev), sh.to(dev), quats.to(dev), raw_opac.to(dev), log_scales.to(dev))
+    cfg = brush_amd.TrainConfig(warmup_steps=0, refine_every=100)
+    tr = brush_amd.SplatTrainer(splats, cfg)
+    tr.iter = 201  # refine step 2: no opacity reset
+    # mean 2-D gradient: big for 0, 1 (clone), 2 (clone, then pruned by opacity), 4, 5 (split), 7 (split, pruned by scale)
+    tr.grad_2d_accum = torch.tensor([1e-3, 4e-4, 1.0, 1e-4, 1.0, 6e-4, 1e-4, 1.0], device=dev)
+    tr.xy_grad_counts = torch.tensor([1.0, 2.0, 1.0, 1.0, 0.0, 3.0, 1.0, 1.0], device=dev)
+    pre = {"means": (means + 100.0).to(dev), "rotation": (quats * 2).to(dev), "sh": (sh + 1).to(dev),
+           "opac": (raw_opac + 0.5).to(dev), "scales": (log_scales - 1).to(dev)}
+    tr.moment1 += 1.0
+    stats = tr.refine_splats(splats, pre)
+    assert (stats.num_cloned, stats.num_split) == (3, 3)          # clones 0,1,2; splits 4,5,7
+    assert stats.num_transparent_pruned == 2                       # splat 2 and its clone (pre-step opacity -6.5)
+    assert stats.num_scale_pruned == 3                             # cumulative (train.rs:551): + splat 7; its child is 6/1.6 = 3.75
+    keep = [0, 1, 3, 4, 5, 6]
+    assert splats.num_splats() == 11
+    f = lambda t: t.detach().cpu()
+    assert torch.equal(f(splats.means)[:6], means[keep]) and torch.equal(f(splats.log_scales)[:6], log_scales[keep])
+    assert torch.equal(f(splats.raw_opacity)[:6], raw_opac[keep])            # no opacity reset on refine step 2
+    assert torch.equal(f(splats.means)[6:8], means[[0, 1]] + 100.0)             # clones: pre-step parameters
+    assert torch.equal(f(splats.rotation)[6:8], quats[[0, 1]] * 2) and torch.equal(f(splats.sh_coeffs)[6:8], sh[[0, 1]] + 1)
+    assert torch.equal(f(splats.raw_opacity)[6:8], raw_opac[[0, 1]] + 0.5)
+    sp = [4, 5, 7]
+    assert torch.equal(f(splats.rotation)[8:], quats[sp]) and torch.equal(f(splats.sh_coeffs)[8:], sh[sp])
+    assert torch.allclose(f(splats.log_scales)[8:], torch.log(log_scales[sp].exp() / 1.6), atol=1e-6)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(cfg.seed)
+    torch.randn((3, 3), generator=gen, device=dev)                              # the dropped source re-sample
+    off = quaternion_vec_multiply(quats[sp].to(dev), torch.randn((3, 3), generator=gen, device=dev) * 0.5
+                                  * log_scales[sp].exp().to(dev))
+    assert torch.allclose(splats.means.detach()[8:], (means[sp] + 100.0).to(dev) + off, atol=1e-5)
+    assert tr.grad_2d_accum.shape == (11,) and float(tr.grad_2d_accum.abs().sum()) == 0.0
+    assert tr.moment1.numel() == 11 * (11 + 3 * ncoef) and float(tr.moment1.abs().sum()) == 0.0 and tr.opt_time == 0
+    assert splats.xys_dummy.shape == (11, 2)
+    tr.iter = 1                                                                  # refine step 0: opacity reset
+    tr.refine_splats(splats, {"means": splats.means.detach(), "rotation": splats.rotation.detach(),
+                              "sh": splats.sh_coeffs.detach(), "opac": splats.raw_opacity.detach(),
+                              "scales": splats.log_scales.detach()})
+    assert torch.allclose(torch.sigmoid(splats.raw_opacity.detach()), torch.full((11,), 0.004, device=dev), atol=1e-6)
+
+
+def test_training_with_refinement_runs(dev):
+    """step() drives refine_splats on iterations with iter % refine_every == 1 and keeps training on the
+    re-sized cloud (Adam state and statistics re-created)."""
+    import torch
+
+    import brush_amd
+
+    cloud = H.synthetic_cloud(2000, 1, seed=5, mean_mult=0.0005)
+    cloud["log_scales"] = cloud["log_scales"] - 3.0
+    w, h = 96, 64
+    c = H.reference_test_camera(w, h)
+    cam = brush_amd.Camera(c["position"], c["rotation_xyzw"], c["fov_x"], c["fov_y"], c["center_uv"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    splats = brush_amd.Splats(t(cloud["means"]), t(cloud["sh"]), t(cloud["quats"]), t(cloud["raw_opac"]), t(cloud["log_scales"]))
+    cfg = brush_amd.TrainConfig(warmup_steps=3, refine_every=3, densify_grad_thresh=1e-6, densify_size_thresh=0.05,
+                                reset_alpha_every_refine=1000)
+    tr = brush_amd.SplatTrainer(splats, cfg)
+    torch.manual_seed(0)
+    gt = torch.rand((h, w, 3), device=dev)
+    sizes, refined = [], []
+    for i in range(8):
+        loss, pred, aux = tr.step(splats, cam, gt)
+        assert math.isfinite(float(loss))
+        sizes.append(splats.num_splats())
+        refined.append(tr.last_refine)
+    assert [r is not None for r in refined] == [False, False, False, False, True, False, False, True]
+    first = refined[4]
+    assert first.num_cloned + first.num_split > 0
+    assert sizes[3] == 2000 and sizes[4] == 2000 + first.num_cloned + first.num_split - first.num_scale_pruned
+    assert tr.moment1.numel() == splats.num_splats() * (11 + 3 * 4) and tr.opt_time == 0
