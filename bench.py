@@ -230,7 +230,7 @@ def main():
     train = None
     if args.train_steps > 0 and world == 1:  # secondary figure, single GPU only
         splats = brush_amd.Splats(p["means"], p["sh"], p["quats"], p["raw_opac"], p["log_scales"])
-        trainer = brush_amd.SplatTrainer(splats, brush_amd.TrainConfig(warmup_steps=0))
+        trainer = brush_amd.SplatTrainer(splats, brush_amd.TrainConfig(warmup_steps=0, max_refine_step=0))
         gt = torch.rand((h, w, 3), dtype=torch.float32, device=dev)  # synthetic target image
 
         for _ in range(3):

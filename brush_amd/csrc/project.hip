@@ -56,6 +56,8 @@ struct WalkQueue {
                             //     (hit mask in inline_mask) or kInlineRetest
     uint64_t *inline_mask;  // [N] hit mask of an inline splat's <= 64 bbox tiles (row-major)
     uint32_t capacity;
+    uint32_t *scan_sums;    // [ceil(N/1024)] sums of tiles_hit per scan tile (zeroed by the cull kernel), or nullptr
+    uint32_t scan_tiles;
 };
 // The count pass records WHICH tiles passed, so the emit pass never repeats the exact test.
 constexpr uint32_t kInlineFlag = 0x80000000u;
@@ -165,7 +167,8 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                                            uint32_t *__restrict__ num_intersections,
                                                            uint32_t *__restrict__ overflow,
                                                            uint32_t *__restrict__ tile_bins, uint32_t num_bin_words,
-                                                           uint32_t *__restrict__ walk_counter) {
+                                                           uint32_t *__restrict__ walk_counter,
+                                                           uint32_t *__restrict__ scan_sums, uint32_t scan_tiles) {
     __shared__ uint32_t wave_cnt[kThreads / kWave];
     const uint32_t gt = blockIdx.x * kThreads + threadIdx.x;
     if (gt < kUniformWords) uniforms_buffer[gt] = reinterpret_cast<const uint32_t *>(&u)[gt];
@@ -175,6 +178,8 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
         *walk_counter = 0;
     }
     for (uint32_t i = gt; i < num_bin_words; i += gridDim.x * kThreads) tile_bins[i] = 0;  // render.rs:241-244
+    if (scan_sums)
+        for (uint32_t i = gt; i < scan_tiles; i += gridDim.x * kThreads) scan_sums[i] = 0;
 
     // kCullPerThread independent splats per lane (round r covers 256 consecutive splats).
     uint32_t block_visible = 0;
@@ -263,11 +268,25 @@ __global__ __launch_bounds__(1024) void k_cull_scan(uint32_t *__restrict__ block
 }
 
 // Order-preserving compaction of (depth key, global id); same 1024-splat partition as the cull.
+// SELF_SCAN: block_offsets holds the raw per-block counts and every block sums the counts of the
+// blocks before it (<= kSelfScanBlocks of them), the last block publishing the total; this saves the
+// k_cull_scan launch for clouds up to 2M splats.
+template <bool SELF_SCAN>
 __global__ __launch_bounds__(kThreads) void k_compact(uint32_t n, const uint32_t *__restrict__ key_all,
                                                       const uint32_t *__restrict__ block_offsets,
-                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ gids) {
+                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ gids,
+                                                      uint32_t *__restrict__ num_visible,
+                                                      uint32_t *__restrict__ uniforms_buffer) {
     __shared__ uint32_t wave_cnt[kCullPerThread][kThreads / kWave];
+    __shared__ uint32_t pre_s[kThreads / kWave];
     const uint32_t wid = threadIdx.x / kWave;
+    uint32_t before = 0;
+    if (SELF_SCAN) {
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kThreads) before += block_offsets[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+        if (lane_id() == 0) pre_s[wid] = before;
+    }
     uint32_t key[kCullPerThread];
     uint64_t bal[kCullPerThread];
 #pragma unroll
@@ -278,7 +297,17 @@ __global__ __launch_bounds__(kThreads) void k_compact(uint32_t n, const uint32_t
         if (lane_id() == 0) wave_cnt[r][wid] = __popcll(bal[r]);
     }
     __syncthreads();
-    uint32_t off = block_offsets[blockIdx.x];
+    uint32_t off;
+    if (SELF_SCAN) {
+        off = pre_s[0] + pre_s[1] + pre_s[2] + pre_s[3];
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+            const uint32_t total = off + block_offsets[blockIdx.x];
+            *num_visible = total;
+            uniforms_buffer[kNumVisibleWord] = total;
+        }
+    } else {
+        off = block_offsets[blockIdx.x];
+    }
 #pragma unroll
     for (uint32_t r = 0; r < kCullPerThread; r++) {
         uint32_t mine = off + __popcll(bal[r] & lanemask_lt());
@@ -425,6 +454,12 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
             p[8] = opac;
             tiles_hit[c] = area;
         }
+        if (q.scan_sums) {  // a wave's 64 compact ids share one 1024-element scan tile
+            uint32_t wsum = active ? area : 0u;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+            if (lane_id() == 0 && wsum) atomicAdd(&q.scan_sums[(base + threadIdx.x) / kScanTileElems], wsum);
+        }
     }
 }
 
@@ -451,7 +486,10 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
         if (lane < kChunkTiles / kWave) q.chunk_mask[(size_t)it * (kChunkTiles / kWave) + lane] = my_mask;
         if (lane == 0) {
             q.chunk_count[it] = cnt;
-            if (cnt) atomicAdd(&tiles_hit[item.x], cnt);
+            if (cnt) {
+                atomicAdd(&tiles_hit[item.x], cnt);
+                if (q.scan_sums) atomicAdd(&q.scan_sums[item.x / kScanTileElems], cnt);
+            }
         }
     }
 }
@@ -568,17 +606,21 @@ WalkQueue make_queue(const WalkWs &w) {
     q.slot_of = w.slot_of;
     q.inline_mask = reinterpret_cast<uint64_t *>(w.inline_mask);
     q.capacity = w.capacity;
+    q.scan_sums = w.scan_sums;
+    q.scan_tiles = w.scan_tiles;
     return q;
 }
 
 }  // namespace
+
+constexpr uint32_t kSelfScanBlocks = 2048;
 
 size_t cull_block_count(uint32_t n) { return ceil_div(n ? n : 1, kCullBlock); }
 
 hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, const BrushAux &aux,
                                uint32_t num_tiles, const float *means, const float *log_scales,
                                const float *quats, uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
-                               uint32_t *gids, uint32_t *walk_counter, hipStream_t s) {
+                               uint32_t *gids, const WalkWs &walk, hipStream_t s) {
     const uint32_t n = vp.total_splats;
     const uint32_t blocks = (uint32_t)cull_block_count(n);
     uint32_t *compact_from_global = aux.compact_from_global_gid;
@@ -586,10 +628,16 @@ hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, con
     uint32_t *uniforms_buffer = aux.uniforms_buffer;
     hipLaunchKernelGGL(k_project_cull, dim3(blocks), dim3(kThreads), 0, s, vp, u, means, log_scales, quats, key_all,
                        compact_from_global, block_counts, uniforms_buffer, aux.num_intersections, aux.overflow,
-                       aux.tile_bins, num_tiles * 2, walk_counter);
-    hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, s, block_counts, blocks, num_visible,
-                       uniforms_buffer);
-    hipLaunchKernelGGL(k_compact, dim3(blocks), dim3(kThreads), 0, s, n, key_all, block_counts, keys, gids);
+                       aux.tile_bins, num_tiles * 2, walk.counter, walk.scan_sums, walk.scan_tiles);
+    if (blocks <= kSelfScanBlocks) {
+        hipLaunchKernelGGL(k_compact<true>, dim3(blocks), dim3(kThreads), 0, s, n, key_all, block_counts, keys, gids,
+                           num_visible, uniforms_buffer);
+    } else {
+        hipLaunchKernelGGL(k_cull_scan, dim3(1), dim3(1024), 0, s, block_counts, blocks, num_visible,
+                           uniforms_buffer);
+        hipLaunchKernelGGL(k_compact<false>, dim3(blocks), dim3(kThreads), 0, s, n, key_all, block_counts, keys, gids,
+                           num_visible, uniforms_buffer);
+    }
     return hipGetLastError();
 }
 

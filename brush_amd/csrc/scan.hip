@@ -3,7 +3,9 @@
 // Reference: prefix_sum() crates/brush-prefix-sum/src/lib.rs:17-102 — 512-wide Hillis-Steele
 // per workgroup, recursive block sums, 5 launches at N = 1 M.
 //
-// gfx950 design: reduce-then-scan in three launches for any n.
+// gfx950 design: reduce-then-scan.  Up to 2048 tiles (2 M elements) every scan block sums the tile
+// sums before it itself (two launches; ONE when the producer already accumulated the tile sums, as
+// the render path's tile counters do); beyond that a single-block spine scans them (three launches).
 //   k_reduce : one 256-thread block per 1024-element tile, one coalesced dwordx4 per lane,
 //              wave64 shuffle reduction -> tile_sums[t]
 //   k_spine  : one 1024-thread block scans tile_sums in place (exclusive), 1024 at a time with
@@ -19,6 +21,7 @@ namespace {
 
 constexpr uint32_t kScanThreads = 256;
 constexpr uint32_t kScanTile = kScanThreads * 4;
+static_assert(kScanTile == kScanTileElems, "producers pre-sum per kScanTileElems");
 
 __device__ __forceinline__ uint4 load_tile4(const uint32_t *__restrict__ in, uint32_t idx, uint32_t n,
                                             uint32_t valid_n, bool aligned) {
@@ -85,11 +88,24 @@ __global__ __launch_bounds__(1024) void k_scan_spine(uint32_t *__restrict__ tile
     }
 }
 
+// SELF: `tile_prefix` holds the raw tile sums; the block adds up those before it, and the last block
+// publishes the grand total (clamped to cap, flagging the overflow).
+template <bool SELF>
 __global__ __launch_bounds__(kScanThreads) void k_scan_down(const uint32_t *__restrict__ in,
                                                            uint32_t *__restrict__ out, uint32_t n,
                                                            const uint32_t *__restrict__ d_valid_n,
-                                                           const uint32_t *__restrict__ tile_prefix) {
+                                                           const uint32_t *__restrict__ tile_prefix,
+                                                           uint32_t *__restrict__ d_total, uint32_t cap,
+                                                           uint32_t *__restrict__ d_overflow) {
     __shared__ uint32_t wave_tot[kScanThreads / kWave];
+    __shared__ uint32_t pre_s[kScanThreads / kWave];
+    if (SELF) {
+        uint32_t before = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kScanThreads) before += tile_prefix[i];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+        if (lane_id() == 0) pre_s[threadIdx.x / kWave] = before;
+    }
     const uint32_t valid_n = d_valid_n ? min(*d_valid_n, n) : n;
     const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
     const uint32_t idx = blockIdx.x * kScanTile + threadIdx.x * 4;
@@ -101,7 +117,17 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_down(const uint32_t *__re
     const uint32_t wid = threadIdx.x / kWave;
     if (lane_id() == 63) wave_tot[wid] = incl;
     __syncthreads();
-    uint32_t off = tile_prefix[blockIdx.x] + (incl - v.w);
+    const uint32_t prefix = SELF ? pre_s[0] + pre_s[1] + pre_s[2] + pre_s[3] : tile_prefix[blockIdx.x];
+    if (SELF && d_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const uint32_t total = prefix + wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        if (total > cap) {
+            *d_total = cap;
+            if (d_overflow) *d_overflow = 1u;
+        } else {
+            *d_total = total;
+        }
+    }
+    uint32_t off = prefix + (incl - v.w);
     for (uint32_t w = 0; w < wid; w++) off += wave_tot[w];
     v.x += off;
     v.y += off;
@@ -124,20 +150,31 @@ size_t scan_workspace_bytes(uint32_t n) {
     return align_up((size_t)ceil_div(n ? n : 1, kScanTile) * sizeof(uint32_t), 256);
 }
 
+constexpr uint32_t kSelfScanTiles = 2048;
+
+uint32_t scan_tile_count(uint32_t n) { return ceil_div(n, kScanTile); }
+bool scan_accepts_presummed(uint32_t n) { return n > 0 && ceil_div(n, kScanTile) <= kSelfScanTiles; }
+
 hipError_t scan_launch(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_valid_n,
-                       uint32_t *d_total, uint32_t cap, uint32_t *d_overflow, void *ws, hipStream_t s) {
+                       uint32_t *d_total, uint32_t cap, uint32_t *d_overflow, void *ws, hipStream_t s,
+                       bool presummed) {
     uint32_t *tile_sums = static_cast<uint32_t *>(ws);
     const uint32_t num_tiles = ceil_div(n, kScanTile);
-    if (n > 0) {
-        hipLaunchKernelGGL(k_scan_reduce, dim3(num_tiles), dim3(kScanThreads), 0, s, in, n, d_valid_n,
-                           tile_sums);
+    if (n == 0) {  // nothing to scan: the spine still writes d_total = 0
+        hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, tile_sums, 0u, d_total, cap, d_overflow);
+        return hipGetLastError();
     }
-    // The spine also runs for n == 0 so that d_total is always written.
+    if (num_tiles <= kSelfScanTiles) {
+        if (!presummed)
+            hipLaunchKernelGGL(k_scan_reduce, dim3(num_tiles), dim3(kScanThreads), 0, s, in, n, d_valid_n, tile_sums);
+        hipLaunchKernelGGL(k_scan_down<true>, dim3(num_tiles), dim3(kScanThreads), 0, s, in, out, n, d_valid_n,
+                           tile_sums, d_total, cap, d_overflow);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_scan_reduce, dim3(num_tiles), dim3(kScanThreads), 0, s, in, n, d_valid_n, tile_sums);
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, tile_sums, num_tiles, d_total, cap, d_overflow);
-    if (n > 0) {
-        hipLaunchKernelGGL(k_scan_down, dim3(num_tiles), dim3(kScanThreads), 0, s, in, out, n, d_valid_n,
-                           tile_sums);
-    }
+    hipLaunchKernelGGL(k_scan_down<false>, dim3(num_tiles), dim3(kScanThreads), 0, s, in, out, n, d_valid_n,
+                       tile_sums, d_total, cap, d_overflow);
     return hipGetLastError();
 }
 
@@ -157,6 +194,6 @@ extern "C" int brush_inclusive_scan_u32(const uint32_t *in, uint32_t *out, uint3
     if (!in || !out || !workspace) return BRUSH_ERR_INVALID_ARG;
     if (workspace_bytes < scan_workspace_bytes(n)) return BRUSH_ERR_WORKSPACE_SMALL;
     BRUSH_HIP_CHECK(scan_launch(in, out, n, nullptr, nullptr, 0xFFFFFFFFu, nullptr, workspace,
-                                static_cast<hipStream_t>(stream)));
+                                static_cast<hipStream_t>(stream), false));
     return BRUSH_OK;
 }

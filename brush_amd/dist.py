@@ -218,15 +218,16 @@ def allreduce_param_grads_compact(block: torch.Tensor, aux: RenderAux, means: to
         return block
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = block.device
-    counts = torch.empty(world, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(counts, aux.num_visible.reshape(-1)[:1].to(torch.int32).clone(), group=group)
-    rows = max(256, -(-int(counts.max().item()) // 256) * 256)
+    # one small message per rank: [num_visible | viewmat[3].xyz bits] (SURVEY §2b-1 for the camera term)
+    meta = torch.cat([aux.num_visible.reshape(-1)[:1].to(torch.int32), aux.uniforms_buffer[12:15].to(torch.int32)])
+    metas = torch.empty((world, 4), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(metas.view(-1), meta, group=group)
+    counts = metas[:, 0].contiguous()
+    cams = metas[:, 1:4].contiguous().view(torch.float32)
+    rows = max(256, -(-int(counts.max().item()) // 256) * 256)  # host read: sizes the padded exchange
     rec = (pack or pack_view_records)(block, aux, n, ncoef, rows)
-    words = aux.uniforms_buffer[12:15].contiguous().view(torch.float32).clone()  # viewmat[3].xyz
     recs = torch.empty((world, rows, _REC), dtype=torch.float32, device=dev)
-    cams = torch.empty((world, 3), dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(recs.view(-1), rec.view(-1), group=group)
-    dist.all_gather_into_tensor(cams.view(-1), words, group=group)
     return (expand or expand_view_records)(recs, counts, cams, means, block, n, ncoef, rank)
 
 

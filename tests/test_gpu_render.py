@@ -290,6 +290,16 @@ def test_walk_queue_overflow_falls_back_inline(dev):
     _assert_grad_parity(gpu, orc)
 
 
+def test_cloud_above_self_scan_limit(dev):
+    """2.4 M splats: more than 2048 cull workgroups, i.e. the separate block-count scan launch instead
+    of the in-compaction scan used for smaller clouds; forward state bit-exact against the oracle."""
+    cloud = H.synthetic_cloud(2_400_000, 0, seed=7, mean_mult=1.0)
+    gpu, orc = _run_pair(dev, cloud, 640, 360, 0, max_intersects=4_000_000)
+    V, I = _assert_forward_parity(gpu, orc, 640, 360)
+    assert V > 50000 and I > V
+    _assert_grad_parity(gpu, orc)
+
+
 def test_4k_frame(dev):
     """3840x2160 (240x135 tiles, 15-bit tile ids -> 16 sorted bits, SURVEY §8 c5 resolution)."""
     cloud = H.synthetic_cloud(120000, 0, seed=4, mean_mult=1.0)

@@ -11,7 +11,7 @@ p = {k: torch.from_numpy(v).to(dev) for k, v in cloud.items()}
 c = H.reference_test_camera(w, h)
 cam = brush_amd.Camera(c["position"], c["rotation_xyzw"], c["fov_x"], c["fov_y"], c["center_uv"])
 splats = brush_amd.Splats(p["means"], p["sh"], p["quats"], p["raw_opac"], p["log_scales"])
-trainer = brush_amd.SplatTrainer(splats, brush_amd.TrainConfig(warmup_steps=0))
+trainer = brush_amd.SplatTrainer(splats, brush_amd.TrainConfig(warmup_steps=0, max_refine_step=0))
 gt = torch.rand((h, w, 3), dtype=torch.float32, device=dev)
 for _ in range(3):
     trainer.step(splats, cam, gt)
