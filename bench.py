@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+VALU_PEAK_GINST = 614.4  # wave64 VALU instructions/s: 256 CUs * 4 SIMDs * 2.4 GHz / 4 cycles
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
@@ -198,16 +199,25 @@ def main():
     dominant = max(("rasterize", "rasterize_bwd", "project_bwd", "project_visible"), key=lambda k: stage_ms[k])
     dom_bytes = stage_bytes(dominant, n, V, I, P, T, C)
     achieved = dom_bytes / (stage_ms[dominant] * 1e-3) / 1e9 if stage_ms[dominant] > 0 else 0.0
-    traffic = None
+    traffic, valu = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dominant)
+            tj = json.load(open(tpath))
+            traffic = tj.get(dominant)
+            insts = tj.get("valu_insts", {}).get(dominant)
+            if insts and stage_ms[dominant] > 0:
+                # The ceiling that actually binds the compositing kernels: one non-packed
+                # wave64 VALU instruction occupies a SIMD for 4 cycles -> 1024 SIMDs * 2.4 GHz / 4.
+                rate = insts / (stage_ms[dominant] * 1e-3) / 1e9
+                valu = {"insts_per_launch": int(insts), "achieved_Ginst_s": round(rate, 1), "peak_Ginst_s": VALU_PEAK_GINST,
+                        "frac": round(rate / VALU_PEAK_GINST, 4),
+                        "note": "SQ_INSTS_VALU per launch from profiles/ (rocprofv3 --pmc) / live kernel time"}
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(stage_ms[dominant], 5)}
+                "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(stage_ms[dominant], 5), "valu_issue": valu}
     # Device-to-device copy bandwidth measured in the same run: 1 GiB read + 1 GiB write.
     src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
     dst = torch.empty_like(src)

@@ -66,14 +66,8 @@ size_t scan_workspace_bytes(uint32_t n);
 // Inclusive scan of in[0..n) -> out. If d_valid_n != nullptr, elements >= *d_valid_n read as 0.
 // If d_total != nullptr, the grand total (out[n-1]) is also written there, clamped to `cap`
 // with *d_overflow set when it exceeded cap (pass cap = 0xFFFFFFFF / nullptr to disable).
-// presummed: ws already holds the per-tile sums (tiles of kScanTileElems elements, only valid when
-// scan_accepts_presummed(n)); the producer accumulated them, so the reduce launch is skipped.
 hipError_t scan_launch(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_valid_n,
-                       uint32_t *d_total, uint32_t cap, uint32_t *d_overflow, void *ws, hipStream_t s,
-                       bool presummed);
-constexpr uint32_t kScanTileElems = 1024;
-uint32_t scan_tile_count(uint32_t n);
-bool scan_accepts_presummed(uint32_t n);
+                       uint32_t *d_total, uint32_t cap, uint32_t *d_overflow, void *ws, hipStream_t s);
 
 // radix_sort.hip
 size_t sort_workspace_bytes(uint32_t max_n);

@@ -16,19 +16,16 @@ struct WalkWs {
     uint32_t *slot_of;      // [N]
     uint32_t *inline_mask;  // [N * 2] (64-bit hit mask per inline splat)
     uint32_t capacity;
-    uint32_t *scan_sums;    // per-1024-splat sums of tiles_hit for the prefix sum, or nullptr
-    uint32_t scan_tiles;
 };
 size_t cull_block_count(uint32_t n);
 hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, const BrushAux &aux,
                                uint32_t num_tiles, const float *means, const float *log_scales,
-                               const float *quats, uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
+                               const float *quats, const float *sh, const float *raw_opac, float *proj_global,
+                               uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
                                uint32_t *gids, const WalkWs &walk, hipStream_t s);
-hipError_t launch_project_visible(const ViewParams &vp, const float *means, const float *log_scales,
-                                  const float *quats, const float *sh, const float *raw_opac,
-                                  const uint32_t *num_visible, uint32_t *global_from_compact,
-                                  uint32_t *compact_from_global, float *projected, uint32_t *tiles_hit,
-                                  const WalkWs &walk, hipStream_t s);
+hipError_t launch_project_visible(const ViewParams &vp, const float *proj_global, const uint32_t *num_visible,
+                                  uint32_t *global_from_compact, uint32_t *compact_from_global, float *projected,
+                                  uint32_t *tiles_hit, const WalkWs &walk, hipStream_t s);
 hipError_t launch_map_intersects(const ViewParams &vp, const float *projected, const uint32_t *cum_tiles_hit,
                                  const uint32_t *num_visible, uint32_t cap, uint32_t *tile_ids, uint32_t *gids,
                                  const WalkWs &walk, hipStream_t s);

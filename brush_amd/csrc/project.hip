@@ -33,7 +33,7 @@ constexpr uint32_t kCullPerThread = 4;                     // splats per lane in
 constexpr uint32_t kCullBlock = kThreads * kCullPerThread;  // splats per cull workgroup
 // Tile walks.  A splat's bbox holds 1 .. tiles_x*tiles_y candidate tiles and the exact
 // can_be_visible test costs ~300 VALU instructions, so the walk is split by size:
-//   * bboxes of <= kSmallArea (64) tiles are walked inside project_visible, but not lane by lane:
+//   * bboxes of <= kSmallArea (16) tiles are walked inside project_visible, but not lane by lane:
 //     the candidate tiles of the wave's 64 splats are flattened into one list (wave prefix sum of
 //     the bbox areas), every lane tests one candidate per step after finding its owner splat with
 //     a 6-step shuffle binary search, and each owner harvests its hit bits from the step's ballot
@@ -44,7 +44,7 @@ constexpr uint32_t kCullBlock = kThreads * kCullPerThread;  // splats per cull w
 //     waves.
 // If the queue is full the lane falls back to walking its bbox inline (slow, still correct).
 // The hit masks are kept so that the emission pass never repeats the exact test.
-constexpr uint32_t kSmallArea = 64;
+constexpr uint32_t kSmallArea = 16;
 constexpr uint32_t kChunkTiles = 256;
 
 struct WalkQueue {
@@ -56,8 +56,6 @@ struct WalkQueue {
                             //     (hit mask in inline_mask) or kInlineRetest
     uint64_t *inline_mask;  // [N] hit mask of an inline splat's <= 64 bbox tiles (row-major)
     uint32_t capacity;
-    uint32_t *scan_sums;    // [ceil(N/1024)] sums of tiles_hit per scan tile (zeroed by the cull kernel), or nullptr
-    uint32_t scan_tiles;
 };
 // The count pass records WHICH tiles passed, so the emit pass never repeats the exact test.
 constexpr uint32_t kInlineFlag = 0x80000000u;
@@ -156,10 +154,58 @@ __device__ __forceinline__ SplatWalk load_walk(const ViewParams &vp, const float
 // project_forward.wgsl:15-68.  One splat per lane; 40 B read, 8 B written per splat.  Being the
 // first launch of the forward pass it also publishes the uniforms buffer and clears the counters
 // and tile_bins (render.rs:102-116,241-244) so that no separate init launch is needed.
+// SH -> colour with the WGSL expression tree (project_visible.wgsl:51-147,232-241).
+template <int DEG>
+__device__ __forceinline__ void sh_colour(const ViewParams &vp, const float mean[3], const float *__restrict__ sh,
+                                          float rgb[3]) {
+    constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);  // compile-time: all SH loads issue together
+    float dir[3];
+    view_dir(vp, mean, dir);
+    float Y[ncoef];
+    sh_basis<ncoef>(DEG, dir, Y);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        float col = Y[0] * sh[ch];
+        if (DEG >= 1) {
+            const float inner = ((-dir[1]) * sh[1 * 3 + ch] + dir[2] * sh[2 * 3 + ch]) - dir[0] * sh[3 * 3 + ch];
+            col = col + 0.48860251190292f * inner;
+        }
+        if (DEG >= 2) {
+            float acc = Y[4] * sh[4 * 3 + ch];
+#pragma unroll
+            for (int k = 5; k < 9; k++) acc = acc + Y[k] * sh[k * 3 + ch];
+            col = col + acc;
+        }
+        if (DEG >= 3) {
+            float acc = Y[9] * sh[9 * 3 + ch];
+#pragma unroll
+            for (int k = 10; k < 16; k++) acc = acc + Y[k] * sh[k * 3 + ch];
+            col = col + acc;
+        }
+        if (DEG >= 4) {
+            float acc = Y[16] * sh[16 * 3 + ch];
+#pragma unroll
+            for (int k = 17; k < 25; k++) acc = acc + Y[k] * sh[k * 3 + ch];
+            col = col + acc;
+        }
+        rgb[ch] = col + 0.5f;
+    }
+}
+
+// The splat's ProjectedSplat record (project_visible.wgsl:163-258) is produced HERE, for every splat
+// that passes the cull, while its parameters stream through in global-id order: the reference (and
+// an earlier version of this file) recomputes it after the depth sort from seven gathers by global id,
+// which on MI355X is bound by address-translation misses (one page per lane per array), not by
+// bandwidth or arithmetic.  The record goes to a global-id-indexed staging row of 48 bytes;
+// k_project_visible then needs ONE gather per splat.
+template <int DEG>
 __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushUniforms u,
                                                            const float *__restrict__ means,
                                                            const float *__restrict__ log_scales,
                                                            const float *__restrict__ quats,
+                                                           const float *__restrict__ sh_coeffs,
+                                                           const float *__restrict__ raw_opac,
+                                                           float4 *__restrict__ proj_global,
                                                            uint32_t *__restrict__ key_all,
                                                            uint32_t *__restrict__ compact_from_global,
                                                            uint32_t *__restrict__ block_counts,
@@ -167,9 +213,9 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                                            uint32_t *__restrict__ num_intersections,
                                                            uint32_t *__restrict__ overflow,
                                                            uint32_t *__restrict__ tile_bins, uint32_t num_bin_words,
-                                                           uint32_t *__restrict__ walk_counter,
-                                                           uint32_t *__restrict__ scan_sums, uint32_t scan_tiles) {
+                                                           uint32_t *__restrict__ walk_counter) {
     __shared__ uint32_t wave_cnt[kThreads / kWave];
+    __shared__ uint32_t vis_list[kThreads / kWave][kCullPerThread * kWave];  // per wave: global ids that passed
     const uint32_t gt = blockIdx.x * kThreads + threadIdx.x;
     if (gt < kUniformWords) uniforms_buffer[gt] = reinterpret_cast<const uint32_t *>(&u)[gt];
     if (gt == 0) {
@@ -178,10 +224,28 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
         *walk_counter = 0;
     }
     for (uint32_t i = gt; i < num_bin_words; i += gridDim.x * kThreads) tile_bins[i] = 0;  // render.rs:241-244
-    if (scan_sums)
-        for (uint32_t i = gt; i < scan_tiles; i += gridDim.x * kThreads) scan_sums[i] = 0;
 
-    // kCullPerThread independent splats per lane (round r covers 256 consecutive splats).
+    // kCullPerThread independent splats per lane (round r covers 256 consecutive splats).  All 44
+    // bytes of the four splats are requested up front with unconditional (clamped) loads: one memory
+    // phase per wave; the culls below only decide how much arithmetic follows.
+    float mean_r[kCullPerThread][3], lsv_r[kCullPerThread][3], opac_raw[kCullPerThread];
+    float4 q4_r[kCullPerThread];
+    const uint32_t last = vp.total_splats ? vp.total_splats - 1 : 0;
+#pragma unroll
+    for (uint32_t r = 0; r < kCullPerThread; r++) {
+        const size_t g = min(blockIdx.x * kCullBlock + r * kThreads + threadIdx.x, last);
+        if (vp.total_splats) {  // uniform: an empty cloud has no row 0 to clamp to
+#pragma unroll
+            for (int k = 0; k < 3; k++) mean_r[r][k] = means[g * 3 + k], lsv_r[r][k] = log_scales[g * 3 + k];
+            q4_r[r] = reinterpret_cast<const float4 *>(quats)[g];
+            opac_raw[r] = raw_opac[g];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) mean_r[r][k] = 0.0f, lsv_r[r][k] = 0.0f;
+            q4_r[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            opac_raw[r] = 0.0f;
+        }
+    }
     uint32_t block_visible = 0;
 #pragma unroll
     for (uint32_t r = 0; r < kCullPerThread; r++) {
@@ -189,11 +253,9 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
         bool visible = false;
         float depth = 0.0f;
         if (g < vp.total_splats) {
-            // All 40 bytes of the splat are requested up front (one memory phase per wave instead of
-            // three dependent ones); the culls below only decide how much arithmetic follows.
-            const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
-            const float lsv[3] = {log_scales[(size_t)g * 3], log_scales[(size_t)g * 3 + 1], log_scales[(size_t)g * 3 + 2]};
-            const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
+            const float mean[3] = {mean_r[r][0], mean_r[r][1], mean_r[r][2]};
+            const float lsv[3] = {lsv_r[r][0], lsv_r[r][1], lsv_r[r][2]};
+            const float4 q4 = q4_r[r];
             float p_view[3];
             to_view(vp, mean, p_view);
             bool maybe = p_view[2] > 0.01f;  // :32
@@ -227,13 +289,32 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                     if ((bb[2] - bb[0]) != 0u && (bb[3] - bb[1]) != 0u) {  // :60
                         visible = true;
                         depth = p_view[2];
+                        const float opac = det_sigmoid(opac_raw[r]);
+                        float4 *row = proj_global + (size_t)g * 3;
+                        row[0] = make_float4(xy[0], xy[1], conic[0], conic[1]);
+                        row[1] = make_float4(conic[2], opac, 0.0f, 0.0f);
                     }
                 }
             }
             key_all[g] = visible ? __float_as_uint(depth) : kInvalid;
             compact_from_global[g] = kInvalid;
         }
-        block_visible += __popcll(__ballot(visible));
+        // the few lanes that passed (~10 %) queue their id; the SH evaluation below then runs on full
+        // waves instead of once per round at 10 % lane occupancy
+        const uint64_t bal = __ballot(visible);
+        if (visible) vis_list[threadIdx.x / kWave][block_visible + __popcll(bal & lanemask_lt())] = g;
+        block_visible += __popcll(bal);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < block_visible; base += kWave) {  // wave-uniform
+        const uint32_t i = base + lane_id();
+        if (i < block_visible) {
+            const uint32_t g = vis_list[threadIdx.x / kWave][i];
+            const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
+            float rgb[3];
+            sh_colour<DEG>(vp, mean, sh_coeffs + (size_t)g * ((DEG + 1) * (DEG + 1)) * 3, rgb);
+            proj_global[(size_t)g * 3 + 2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+        }
     }
     if (lane_id() == 0) wave_cnt[threadIdx.x / kWave] = block_visible;
     __syncthreads();
@@ -324,19 +405,16 @@ __global__ __launch_bounds__(kThreads) void k_compact(uint32_t n, const uint32_t
 }
 
 // ---- ProjectVisible ----------------------------------------------------------------------
-// project_visible.wgsl:163-258.  One visible splat per lane (compact = depth order), gathers
-// its parameters by global id; writes ProjectedSplat (36 B), the exact tile count, and the
-// inverse map.  Lanes c >= V clear the tail of global_from_compact_gid.
-template <int DEG>
+// project_visible.wgsl:163-258.  One visible splat per lane (compact = depth order): fetches the
+// record the cull kernel staged under its global id, writes ProjectedSplat (36 B) in compact
+// order, the exact tile count, and the inverse map.  Lanes c >= V clear the tail of
+// global_from_compact_gid.
 __global__ __launch_bounds__(kThreads) void k_project_visible(
-    ViewParams vp, const float *__restrict__ means, const float *__restrict__ log_scales,
-    const float *__restrict__ quats, const float *__restrict__ sh_coeffs, const float *__restrict__ raw_opac,
-    const uint32_t *__restrict__ num_visible, uint32_t *__restrict__ global_from_compact,
-    uint32_t *__restrict__ compact_from_global, float *__restrict__ projected, uint32_t *__restrict__ tiles_hit,
-    WalkQueue q) {
+    ViewParams vp, const float4 *__restrict__ proj_global, const uint32_t *__restrict__ num_visible,
+    uint32_t *__restrict__ global_from_compact, uint32_t *__restrict__ compact_from_global,
+    float *__restrict__ projected, uint32_t *__restrict__ tiles_hit, WalkQueue q) {
     const uint32_t V = *num_visible;
     const uint32_t n = vp.total_splats;
-    constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);  // compile-time: all SH loads issue together
     // Tail of global_from_compact_gid (never written by the sort) := 0.
     for (uint32_t i = V + blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
         global_from_compact[i] = 0;
@@ -353,52 +431,12 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
         if (active) {
             const uint32_t g = global_from_compact[c];
             compact_from_global[g] = c;
-            const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
-            const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
-                                    det_expf(log_scales[(size_t)g * 3 + 2])};
-            const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
-            const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-            opac = det_sigmoid(raw_opac[g]);
-            float p_view[3], cov2d[3];
-            to_view(vp, mean, p_view);
-            calc_cov2d(vp, p_view, scale, quat, cov2d);
-            cov_to_conic(cov2d, conic);
-            project_pix(vp, p_view, xy);
-
-            // SH -> colour, evaluated with the WGSL expression tree (project_visible.wgsl:51-147).
-            float dir[3];
-            view_dir(vp, mean, dir);
-            float Y[ncoef];
-            sh_basis<ncoef>(DEG, dir, Y);
-            const float *sh = sh_coeffs + (size_t)g * ncoef * 3;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                float col = Y[0] * sh[ch];
-                if (DEG >= 1) {
-                    const float inner =
-                        ((-dir[1]) * sh[1 * 3 + ch] + dir[2] * sh[2 * 3 + ch]) - dir[0] * sh[3 * 3 + ch];
-                    col = col + 0.48860251190292f * inner;
-                }
-                if (DEG >= 2) {
-                    float acc = Y[4] * sh[4 * 3 + ch];
-#pragma unroll
-                    for (int k = 5; k < 9; k++) acc = acc + Y[k] * sh[k * 3 + ch];
-                    col = col + acc;
-                }
-                if (DEG >= 3) {
-                    float acc = Y[9] * sh[9 * 3 + ch];
-#pragma unroll
-                    for (int k = 10; k < 16; k++) acc = acc + Y[k] * sh[k * 3 + ch];
-                    col = col + acc;
-                }
-                if (DEG >= 4) {
-                    float acc = Y[16] * sh[16 * 3 + ch];
-#pragma unroll
-                    for (int k = 17; k < 25; k++) acc = acc + Y[k] * sh[k * 3 + ch];
-                    col = col + acc;
-                }
-                rgb[ch] = col + 0.5f;
-            }
+            const float4 *row = proj_global + (size_t)g * 3;
+            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+            xy[0] = r0.x, xy[1] = r0.y;
+            conic[0] = r0.z, conic[1] = r0.w, conic[2] = r1.x;
+            opac = r1.y;
+            rgb[0] = r2.x, rgb[1] = r2.y, rgb[2] = r2.z;
             const uint32_t radius = radius_from_conic(conic);
             get_tile_bbox(xy, radius, vp.tile_bounds, bb);
             tt = make_tile_test(conic, opac);
@@ -454,12 +492,6 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
             p[8] = opac;
             tiles_hit[c] = area;
         }
-        if (q.scan_sums) {  // a wave's 64 compact ids share one 1024-element scan tile
-            uint32_t wsum = active ? area : 0u;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
-            if (lane_id() == 0 && wsum) atomicAdd(&q.scan_sums[(base + threadIdx.x) / kScanTileElems], wsum);
-        }
     }
 }
 
@@ -486,10 +518,7 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
         if (lane < kChunkTiles / kWave) q.chunk_mask[(size_t)it * (kChunkTiles / kWave) + lane] = my_mask;
         if (lane == 0) {
             q.chunk_count[it] = cnt;
-            if (cnt) {
-                atomicAdd(&tiles_hit[item.x], cnt);
-                if (q.scan_sums) atomicAdd(&q.scan_sums[item.x / kScanTileElems], cnt);
-            }
+            if (cnt) atomicAdd(&tiles_hit[item.x], cnt);
         }
     }
 }
@@ -606,8 +635,6 @@ WalkQueue make_queue(const WalkWs &w) {
     q.slot_of = w.slot_of;
     q.inline_mask = reinterpret_cast<uint64_t *>(w.inline_mask);
     q.capacity = w.capacity;
-    q.scan_sums = w.scan_sums;
-    q.scan_tiles = w.scan_tiles;
     return q;
 }
 
@@ -619,16 +646,27 @@ size_t cull_block_count(uint32_t n) { return ceil_div(n ? n : 1, kCullBlock); }
 
 hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, const BrushAux &aux,
                                uint32_t num_tiles, const float *means, const float *log_scales,
-                               const float *quats, uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
+                               const float *quats, const float *sh, const float *raw_opac, float *proj_global,
+                               uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
                                uint32_t *gids, const WalkWs &walk, hipStream_t s) {
     const uint32_t n = vp.total_splats;
     const uint32_t blocks = (uint32_t)cull_block_count(n);
     uint32_t *compact_from_global = aux.compact_from_global_gid;
     uint32_t *num_visible = aux.num_visible;
     uint32_t *uniforms_buffer = aux.uniforms_buffer;
-    hipLaunchKernelGGL(k_project_cull, dim3(blocks), dim3(kThreads), 0, s, vp, u, means, log_scales, quats, key_all,
-                       compact_from_global, block_counts, uniforms_buffer, aux.num_intersections, aux.overflow,
-                       aux.tile_bins, num_tiles * 2, walk.counter, walk.scan_sums, walk.scan_tiles);
+#define BRUSH_LAUNCH_CULL(D)                                                                                     \
+    hipLaunchKernelGGL(k_project_cull<D>, dim3(blocks), dim3(kThreads), 0, s, vp, u, means, log_scales, quats, sh, \
+                       raw_opac, reinterpret_cast<float4 *>(proj_global), key_all, compact_from_global,          \
+                       block_counts, uniforms_buffer, aux.num_intersections, aux.overflow, aux.tile_bins,        \
+                       num_tiles * 2, walk.counter)
+    switch (vp.sh_degree) {
+        case 0: BRUSH_LAUNCH_CULL(0); break;
+        case 1: BRUSH_LAUNCH_CULL(1); break;
+        case 2: BRUSH_LAUNCH_CULL(2); break;
+        case 3: BRUSH_LAUNCH_CULL(3); break;
+        default: BRUSH_LAUNCH_CULL(4); break;
+    }
+#undef BRUSH_LAUNCH_CULL
     if (blocks <= kSelfScanBlocks) {
         hipLaunchKernelGGL(k_compact<true>, dim3(blocks), dim3(kThreads), 0, s, n, key_all, block_counts, keys, gids,
                            num_visible, uniforms_buffer);
@@ -641,24 +679,13 @@ hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, con
     return hipGetLastError();
 }
 
-hipError_t launch_project_visible(const ViewParams &vp, const float *means, const float *log_scales,
-                                  const float *quats, const float *sh, const float *raw_opac,
-                                  const uint32_t *num_visible, uint32_t *global_from_compact,
-                                  uint32_t *compact_from_global, float *projected, uint32_t *tiles_hit,
-                                  const WalkWs &walk, hipStream_t s) {
+hipError_t launch_project_visible(const ViewParams &vp, const float *proj_global, const uint32_t *num_visible,
+                                  uint32_t *global_from_compact, uint32_t *compact_from_global, float *projected,
+                                  uint32_t *tiles_hit, const WalkWs &walk, hipStream_t s) {
     const WalkQueue q = make_queue(walk);
     const dim3 grid(stride_grid(vp.total_splats)), block(kThreads);
-#define BRUSH_LAUNCH_PV(D)                                                                                  \
-    hipLaunchKernelGGL(k_project_visible<D>, grid, block, 0, s, vp, means, log_scales, quats, sh, raw_opac, \
-                       num_visible, global_from_compact, compact_from_global, projected, tiles_hit, q)
-    switch (vp.sh_degree) {
-        case 0: BRUSH_LAUNCH_PV(0); break;
-        case 1: BRUSH_LAUNCH_PV(1); break;
-        case 2: BRUSH_LAUNCH_PV(2); break;
-        case 3: BRUSH_LAUNCH_PV(3); break;
-        default: BRUSH_LAUNCH_PV(4); break;
-    }
-#undef BRUSH_LAUNCH_PV
+    hipLaunchKernelGGL(k_project_visible, grid, block, 0, s, vp, reinterpret_cast<const float4 *>(proj_global),
+                       num_visible, global_from_compact, compact_from_global, projected, tiles_hit, q);
     hipLaunchKernelGGL(k_walk_count, dim3(1024), dim3(kThreads), 0, s, vp, projected, q, tiles_hit);
     return hipGetLastError();
 }

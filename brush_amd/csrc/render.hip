@@ -52,6 +52,7 @@ struct FwdWs {
     uint32_t *pre_gids;      // [N]
     uint32_t *sorted_keys;   // [N]
     uint32_t *tiles_hit;     // [N]
+    float *proj_global;      // [N][12] projected record staged by the cull kernel under the global id
     uint32_t *tile_unsorted; // [cap]
     uint32_t *gid_unsorted;  // [cap]
     uint32_t *tile_sorted;   // [cap]
@@ -71,6 +72,7 @@ FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap) {
     f.pre_gids = c.take<uint32_t>(nn);
     f.sorted_keys = c.take<uint32_t>(nn);
     f.tiles_hit = c.take<uint32_t>(nn);
+    f.proj_global = c.take<float>(nn * 12);
     f.tile_unsorted = c.take<uint32_t>(cc);
     f.gid_unsorted = c.take<uint32_t>(cc);
     f.tile_sorted = c.take<uint32_t>(cc);
@@ -83,9 +85,6 @@ FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap) {
     f.walk.chunk_mask = c.take<uint32_t>(nn * 8);
     f.walk.slot_of = c.take<uint32_t>(nn);
     f.walk.inline_mask = c.take<uint32_t>(nn * 2);
-    // tile sums of the prefix sum, accumulated by the tile-count kernels when the scan takes them
-    f.walk.scan_sums = scan_accepts_presummed(n) ? static_cast<uint32_t *>(f.scan_ws) : nullptr;
-    f.walk.scan_tiles = scan_tile_count(n);
     f.bytes = c.bytes();
     return f;
 }
@@ -188,21 +187,22 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
     mark_fwd(s, 0);
     // uniforms buffer, counters, tile_bins = 0; ProjectSplats + order-preserving compaction
     // (render.rs:102-142)
-    BRUSH_HIP_CHECK(launch_project_cull(vp, u, aux, num_tiles, means, log_scales, quats, ws.key_all,
-                                        ws.block_counts, ws.pre_keys, ws.pre_gids, ws.walk, s));
+    BRUSH_HIP_CHECK(launch_project_cull(vp, u, aux, num_tiles, means, log_scales, quats, sh_coeffs, raw_opacity,
+                                        ws.proj_global, ws.key_all, ws.block_counts, ws.pre_keys, ws.pre_gids,
+                                        ws.walk, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_CULL);
     // DepthSort: keys = f32 depth bits, all 32 bits (render.rs:151-156)
     BRUSH_HIP_CHECK(sort_launch(ws.pre_keys, ws.pre_gids, ws.sorted_keys, aux.global_from_compact_gid,
                                 aux.num_visible, n, 32, ws.sort_ws, s));
     mark_fwd(s, 1 + BRUSH_STAGE_DEPTH_SORT);
     // ProjectVisible (render.rs:161-184)
-    BRUSH_HIP_CHECK(launch_project_visible(vp, means, log_scales, quats, sh_coeffs, raw_opacity, aux.num_visible,
-                                           aux.global_from_compact_gid, aux.compact_from_global_gid,
-                                           aux.projected_splats, ws.tiles_hit, ws.walk, s));
+    BRUSH_HIP_CHECK(launch_project_visible(vp, ws.proj_global, aux.num_visible, aux.global_from_compact_gid,
+                                           aux.compact_from_global_gid, aux.projected_splats, ws.tiles_hit,
+                                           ws.walk, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_VISIBLE);
     // PrefixSum over all N, tail treated as 0 (render.rs:186-192); total -> num_intersections
     BRUSH_HIP_CHECK(scan_launch(ws.tiles_hit, aux.cum_tiles_hit, n, aux.num_visible, aux.num_intersections, cap,
-                                aux.overflow, ws.scan_ws, s, ws.walk.scan_sums != nullptr));
+                                aux.overflow, ws.scan_ws, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PREFIX_SUM);
     // MapGaussiansToIntersect (render.rs:211-223)
     BRUSH_HIP_CHECK(launch_map_intersects(vp, aux.projected_splats, aux.cum_tiles_hit, aux.num_visible, cap,

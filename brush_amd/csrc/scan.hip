@@ -4,8 +4,10 @@
 // per workgroup, recursive block sums, 5 launches at N = 1 M.
 //
 // gfx950 design: reduce-then-scan.  Up to 2048 tiles (2 M elements) every scan block sums the tile
-// sums before it itself (two launches; ONE when the producer already accumulated the tile sums, as
-// the render path's tile counters do); beyond that a single-block spine scans them (three launches).
+// sums before it itself (two launches); beyond that a single-block spine scans them (three launches).
+// (Letting the producers accumulate the tile sums with atomics saves the reduce launch but was
+// slower: near splats share a tile, and ~2000 same-address atomics drain for ~20 us after the last
+// wave of the producing kernel has retired.)
 //   k_reduce : one 256-thread block per 1024-element tile, one coalesced dwordx4 per lane,
 //              wave64 shuffle reduction -> tile_sums[t]
 //   k_spine  : one 1024-thread block scans tile_sums in place (exclusive), 1024 at a time with
@@ -21,7 +23,6 @@ namespace {
 
 constexpr uint32_t kScanThreads = 256;
 constexpr uint32_t kScanTile = kScanThreads * 4;
-static_assert(kScanTile == kScanTileElems, "producers pre-sum per kScanTileElems");
 
 __device__ __forceinline__ uint4 load_tile4(const uint32_t *__restrict__ in, uint32_t idx, uint32_t n,
                                             uint32_t valid_n, bool aligned) {
@@ -152,12 +153,8 @@ size_t scan_workspace_bytes(uint32_t n) {
 
 constexpr uint32_t kSelfScanTiles = 2048;
 
-uint32_t scan_tile_count(uint32_t n) { return ceil_div(n, kScanTile); }
-bool scan_accepts_presummed(uint32_t n) { return n > 0 && ceil_div(n, kScanTile) <= kSelfScanTiles; }
-
 hipError_t scan_launch(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_valid_n,
-                       uint32_t *d_total, uint32_t cap, uint32_t *d_overflow, void *ws, hipStream_t s,
-                       bool presummed) {
+                       uint32_t *d_total, uint32_t cap, uint32_t *d_overflow, void *ws, hipStream_t s) {
     uint32_t *tile_sums = static_cast<uint32_t *>(ws);
     const uint32_t num_tiles = ceil_div(n, kScanTile);
     if (n == 0) {  // nothing to scan: the spine still writes d_total = 0
@@ -165,8 +162,7 @@ hipError_t scan_launch(const uint32_t *in, uint32_t *out, uint32_t n, const uint
         return hipGetLastError();
     }
     if (num_tiles <= kSelfScanTiles) {
-        if (!presummed)
-            hipLaunchKernelGGL(k_scan_reduce, dim3(num_tiles), dim3(kScanThreads), 0, s, in, n, d_valid_n, tile_sums);
+        hipLaunchKernelGGL(k_scan_reduce, dim3(num_tiles), dim3(kScanThreads), 0, s, in, n, d_valid_n, tile_sums);
         hipLaunchKernelGGL(k_scan_down<true>, dim3(num_tiles), dim3(kScanThreads), 0, s, in, out, n, d_valid_n,
                            tile_sums, d_total, cap, d_overflow);
         return hipGetLastError();
@@ -194,6 +190,6 @@ extern "C" int brush_inclusive_scan_u32(const uint32_t *in, uint32_t *out, uint3
     if (!in || !out || !workspace) return BRUSH_ERR_INVALID_ARG;
     if (workspace_bytes < scan_workspace_bytes(n)) return BRUSH_ERR_WORKSPACE_SMALL;
     BRUSH_HIP_CHECK(scan_launch(in, out, n, nullptr, nullptr, 0xFFFFFFFFu, nullptr, workspace,
-                                static_cast<hipStream_t>(stream), false));
+                                static_cast<hipStream_t>(stream)));
     return BRUSH_OK;
 }
