@@ -258,7 +258,8 @@ def main():
         train = {"iters_per_s": round(args.train_steps / tsec, 2), "ms_per_iter": round(tsec * 1e3 / args.train_steps, 4),
                  "views_per_iter": n_gpus, "steps": args.train_steps,
                  "what": "render + L1*0.8-SSIM*0.2 loss + backward + 5 Adam groups (train.rs:211-359), no refinement, "
-                         "fused HIP loss/Adam kernels around the op (brush_l1_ssim_loss, brush_adam_step)"}
+                         "fused HIP loss kernels around the op, Adam inside the backward's last kernel (brush_l1_ssim_loss, "
+                         "brush_render_backward_adam)"}
         del splats, trainer, gt
 
     # ---- CPU baseline: the oracle (a port), rank 0, N=1 only --------------------------------

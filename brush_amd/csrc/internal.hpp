@@ -44,11 +44,20 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
                                      hipStream_t s);
 
 // project_bwd.hip
+// Optimizer state for the fused backward + Adam form (brush_render_backward_adam).
+struct AdamFuse {
+    float *means, *log_scales, *rotation, *raw_opac, *sh;  // parameters, updated in place
+    float *m1, *m2;                                        // [means 3N | log_scales 3N | quats 4N | raw_opac N | sh 3CN]
+    float lr[5];                                           // means, log_scales, rotation, raw_opac, sh (dc)
+    float sh_lerp, beta1, beta2, eps, bc1, bc2;
+    uint32_t quat_vjp, vec_ok;
+};
 hipError_t launch_project_backward(const ViewParams &vp, const float *means, const float *log_scales,
                                    const float *quats, const float *raw_opac,
                                    const uint32_t *compact_from_global, const float *v_compact,
                                    float *v_means, float *v_xy,
-                                   float *v_scales, float *v_quats, float *v_sh, float *v_opac, hipStream_t s);
+                                   float *v_scales, float *v_quats, float *v_sh, float *v_opac,
+                                   const AdamFuse *adam, hipStream_t s);
 hipError_t launch_zero_compact_grads(const uint32_t *num_visible, uint32_t n, float *v_compact, hipStream_t s);
 
 }  // namespace brush

@@ -69,14 +69,40 @@ __global__ __launch_bounds__(kThreads) void k_zero_compact_grads(const uint32_t 
         v_compact[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int DEG>
+// One Adam update of burn 0.16 `Adam::step` (see train_step.hip:k_adam) on element `e` of the moment
+// arrays; returns the stepped parameter value.
+__device__ __forceinline__ float adam_elem(const AdamFuse &a, size_t e, float g, float x, float lr) {
+    const float m = a.m1[e] * a.beta1 + g * (1.0f - a.beta1);
+    const float v = a.m2[e] * a.beta2 + (g * g) * (1.0f - a.beta2);
+    a.m1[e] = m, a.m2[e] = v;
+    return x - ((m / a.bc1) / (sqrtf(v / a.bc2) + a.eps)) * lr;
+}
+__device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4 g, float4 x, float lr) {
+    const float4 mo = *reinterpret_cast<const float4 *>(a.m1 + e), vo = *reinterpret_cast<const float4 *>(a.m2 + e);
+    float4 m, v, r;
+#define BRUSH_ADAM_C(c)                                                        \
+    m.c = mo.c * a.beta1 + g.c * (1.0f - a.beta1);                             \
+    v.c = vo.c * a.beta2 + (g.c * g.c) * (1.0f - a.beta2);                     \
+    r.c = x.c - ((m.c / a.bc1) / (sqrtf(v.c / a.bc2) + a.eps)) * lr;
+    BRUSH_ADAM_C(x) BRUSH_ADAM_C(y) BRUSH_ADAM_C(z) BRUSH_ADAM_C(w)
+#undef BRUSH_ADAM_C
+    *reinterpret_cast<float4 *>(a.m1 + e) = m;
+    *reinterpret_cast<float4 *>(a.m2 + e) = v;
+    return r;
+}
+
+// ADAM: instead of storing the dense parameter gradients, every element goes straight through the
+// optimizer update of its parameter (brush_render_backward_adam): the 52+12C bytes per splat of
+// gradients are never written to nor re-read from HBM.  v_xy is still stored (refinement statistics).
+// In this mode `means`/`log_scales`/`raw_opac` alias the parameters being updated: each lane reads
+// its own splat before the wave writes the same 64 splats, and no other wave touches them.
+template <int DEG, bool ADAM>
 __global__ __launch_bounds__(kThreads) void k_project_backward(
-    ViewParams vp, const float *__restrict__ means, const float *__restrict__ log_scales,
-    const float *__restrict__ quats, const float *__restrict__ raw_opac,
-    const uint32_t *__restrict__ compact_from_global, const float *__restrict__ v_compact,
-    float *__restrict__ v_means,
-    float *__restrict__ v_xy, float *__restrict__ v_scales, float *__restrict__ v_quats,
-    float *__restrict__ v_sh, float *__restrict__ v_opac) {
+    ViewParams vp, const float *means, const float *log_scales, const float *__restrict__ quats,
+    const float *raw_opac, const uint32_t *__restrict__ compact_from_global,
+    const float *__restrict__ v_compact, float *__restrict__ v_means, float *__restrict__ v_xy,
+    float *__restrict__ v_scales, float *__restrict__ v_quats, float *__restrict__ v_sh,
+    float *__restrict__ v_opac, AdamFuse af) {
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
     constexpr uint32_t kRow = ncoef * 3;                 // floats per v_sh row
     constexpr uint32_t kRowPad = kRow | 1u;              // odd LDS row stride: conflict-free column access
@@ -205,16 +231,53 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     }
 
     const uint32_t rows = min(kWave, n - g0);  // rows this wave owns (64 except at the tail)
+    const size_t nn = n;
     if (in_range) {
-        reinterpret_cast<float4 *>(v_quats)[g] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
         reinterpret_cast<float2 *>(v_xy)[g] = make_float2(o_xy[0], o_xy[1]);
-        v_opac[g] = o_opac;
+        if (!ADAM) {
+            reinterpret_cast<float4 *>(v_quats)[g] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
+            v_opac[g] = o_opac;
+        } else {
+            // rotation: the op was fed rot/|rot| (gaussian_splats.rs:174-175); chain v_q to the raw parameter
+            float4 r = reinterpret_cast<const float4 *>(af.rotation)[g];
+            float4 gq = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
+            if (af.quat_vjp) {
+                const float s2 = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+                const float inv_s = 1.0f / sqrtf(s2);
+                const float dot = (gq.x * r.x + gq.y * r.y + gq.z * r.z + gq.w * r.w) * (inv_s * inv_s * inv_s);
+                gq = make_float4(gq.x * inv_s - r.x * dot, gq.y * inv_s - r.y * dot, gq.z * inv_s - r.z * dot,
+                                 gq.w * inv_s - r.w * dot);
+            }
+            const size_t e = 6 * nn + (size_t)g * 4;
+            if (af.vec_ok) {
+                r = adam_elem4(af, e, gq, r, af.lr[2]);
+            } else {
+                r.x = adam_elem(af, e + 0, gq.x, r.x, af.lr[2]);
+                r.y = adam_elem(af, e + 1, gq.y, r.y, af.lr[2]);
+                r.z = adam_elem(af, e + 2, gq.z, r.z, af.lr[2]);
+                r.w = adam_elem(af, e + 3, gq.w, r.w, af.lr[2]);
+            }
+            reinterpret_cast<float4 *>(af.rotation)[g] = r;
+            af.raw_opac[g] = adam_elem(af, 10 * nn + g, o_opac, af.raw_opac[g], af.lr[3]);
+        }
     }
 
     // Copies `rows` rows of ROWF floats (row r at stage[r*STRIDE]) to dst, contiguous across lanes.
-    auto copy_out = [&](float *__restrict__ dst, uint32_t rowf, uint32_t stride) {
+    // ADAM: `dst` is the parameter array, `seg` the segment's offset in the moment arrays; the staged
+    // gradient updates the parameter in place (SH coefficients >= 1 with the lerp of train.rs:336-351).
+    auto copy_out = [&](float *dst, uint32_t rowf, uint32_t stride, size_t seg, float lr, bool is_sh) {
         const uint32_t total = rows * rowf;  // floats; dst is 16-B aligned when g0*rowf % 4 == 0
-        if ((rowf & 3u) == 0 || rows == kWave) {
+        auto one = [&](uint32_t f) {
+            const float gv = stage[(f / rowf) * stride + (f % rowf)];
+            if (!ADAM) {
+                dst[f] = gv;
+            } else {
+                const float x = dst[f];
+                const float st = adam_elem(af, seg + f, gv, x, lr);
+                dst[f] = (is_sh && (f % rowf) >= 3) ? x * (1.0f - af.sh_lerp) + st * af.sh_lerp : st;
+            }
+        };
+        if (((rowf & 3u) == 0 || rows == kWave) && (!ADAM || af.vec_ok)) {
             // float4 path: rowf*64 is a multiple of 4 and the wave's base offset is 16-B aligned
             for (uint32_t j = lane * 4; j < total; j += kWave * 4) {
                 if (j + 4 <= total) {
@@ -225,13 +288,26 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
                         const uint32_t f = j + i;
                         e[i] = stage[(f / rowf) * stride + (f % rowf)];
                     }
-                    *reinterpret_cast<float4 *>(dst + j) = v;
+                    if (!ADAM) {
+                        *reinterpret_cast<float4 *>(dst + j) = v;
+                    } else {
+                        const float4 x = *reinterpret_cast<const float4 *>(dst + j);
+                        float4 st = adam_elem4(af, seg + j, v, x, lr);
+                        if (is_sh) {
+                            const uint32_t k0 = j % rowf;  // position in the SH row; rows are rowf floats
+                            st.x = (k0 + 0) % rowf >= 3 ? x.x * (1.0f - af.sh_lerp) + st.x * af.sh_lerp : st.x;
+                            st.y = (k0 + 1) % rowf >= 3 ? x.y * (1.0f - af.sh_lerp) + st.y * af.sh_lerp : st.y;
+                            st.z = (k0 + 2) % rowf >= 3 ? x.z * (1.0f - af.sh_lerp) + st.z * af.sh_lerp : st.z;
+                            st.w = (k0 + 3) % rowf >= 3 ? x.w * (1.0f - af.sh_lerp) + st.w * af.sh_lerp : st.w;
+                        }
+                        *reinterpret_cast<float4 *>(dst + j) = st;
+                    }
                 } else {
-                    for (uint32_t f = j; f < total; f++) dst[f] = stage[(f / rowf) * stride + (f % rowf)];
+                    for (uint32_t f = j; f < total; f++) one(f);
                 }
             }
         } else {
-            for (uint32_t f = lane; f < total; f += kWave) dst[f] = stage[(f / rowf) * stride + (f % rowf)];
+            for (uint32_t f = lane; f < total; f += kWave) one(f);
         }
     };
 
@@ -245,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
             row[k * 3 + 2] = Y[k] * vcol[2];
         }
         __builtin_amdgcn_wave_barrier();
-        copy_out(v_sh + (size_t)g0 * kRow, kRow, kRowPad);
+        copy_out((ADAM ? af.sh : v_sh) + (size_t)g0 * kRow, kRow, kRowPad, 11 * nn + (size_t)g0 * kRow, af.lr[4], true);
         __builtin_amdgcn_wave_barrier();
     }
     // v_means, v_scales: 3 floats per row
@@ -257,9 +333,9 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
         stage[256 + lane * 4 + 1] = o_scale[1];
         stage[256 + lane * 4 + 2] = o_scale[2];
         __builtin_amdgcn_wave_barrier();
-        copy_out(v_means + (size_t)g0 * 3, 3, 4);
+        copy_out((ADAM ? af.means : v_means) + (size_t)g0 * 3, 3, 4, (size_t)g0 * 3, af.lr[0], false);
         stage += 256;
-        copy_out(v_scales + (size_t)g0 * 3, 3, 4);
+        copy_out((ADAM ? af.log_scales : v_scales) + (size_t)g0 * 3, 3, 4, 3 * nn + (size_t)g0 * 3, af.lr[1], false);
     }
 }
 
@@ -276,12 +352,20 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
                                    const float *quats, const float *raw_opac,
                                    const uint32_t *compact_from_global, const float *v_compact, float *v_means,
                                    float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
-                                   hipStream_t s) {
+                                   const AdamFuse *adam, hipStream_t s) {
     if (vp.total_splats == 0) return hipSuccess;
     const dim3 grid(ceil_div(vp.total_splats, kThreads)), block(kThreads);
-#define BRUSH_LAUNCH_PB(D)                                                                                   \
-    hipLaunchKernelGGL(k_project_backward<D>, grid, block, 0, s, vp, means, log_scales, quats, raw_opac,     \
-                       compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac)
+    AdamFuse af{};
+    if (adam) af = *adam;
+#define BRUSH_LAUNCH_PB(D)                                                                                      \
+    if (adam)                                                                                                   \
+        hipLaunchKernelGGL((k_project_backward<D, true>), grid, block, 0, s, vp, means, log_scales, quats,      \
+                           raw_opac, compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats, v_sh,    \
+                           v_opac, af);                                                                         \
+    else                                                                                                        \
+        hipLaunchKernelGGL((k_project_backward<D, false>), grid, block, 0, s, vp, means, log_scales, quats,     \
+                           raw_opac, compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats, v_sh,    \
+                           v_opac, af)
     switch (vp.sh_degree) {
         case 0: BRUSH_LAUNCH_PB(0); break;
         case 1: BRUSH_LAUNCH_PB(1); break;

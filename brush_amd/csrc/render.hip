@@ -245,16 +245,15 @@ extern "C" int brush_render_forward_rgba8(const BrushUniforms *h_uniforms, const
 
 extern "C" uint32_t brush_rgba8_row_pitch(uint32_t width) { return (width + 63u) / 64u * 64u; }
 
-extern "C" int brush_render_backward(const BrushUniforms *h_uniforms, const BrushAux *h_aux, const float *means,
-                                     const float *log_scales, const float *quats, const float *raw_opacity,
-                                     uint32_t n, const float *out_img, const float *v_out, float *v_means,
-                                     float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
-                                     void *workspace, size_t workspace_bytes, brush_stream_t stream) {
+static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux *h_aux, const float *means,
+                                const float *log_scales, const float *quats, const float *raw_opacity, uint32_t n,
+                                const float *out_img, const float *v_out, float *v_means, float *v_xy,
+                                float *v_scales, float *v_quats, float *v_sh, float *v_opac, const AdamFuse *adam,
+                                void *workspace, size_t workspace_bytes, brush_stream_t stream) {
     if (!uniforms_ok(h_uniforms) || !aux_ok(h_aux, true) || !out_img || !v_out || !workspace)
         return BRUSH_ERR_INVALID_ARG;
-    if (n > 0 && (!means || !log_scales || !quats || !raw_opacity || !v_means || !v_xy || !v_scales || !v_quats ||
-                  !v_sh || !v_opac))
-        return BRUSH_ERR_INVALID_ARG;
+    if (n > 0 && (!means || !log_scales || !quats || !raw_opacity || !v_xy)) return BRUSH_ERR_INVALID_ARG;
+    if (n > 0 && !adam && (!v_means || !v_scales || !v_quats || !v_sh || !v_opac)) return BRUSH_ERR_INVALID_ARG;
     const BrushAux &aux = *h_aux;
     const BwdWs ws = carve_bwd(workspace, n);
     if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
@@ -277,9 +276,44 @@ extern "C" int brush_render_backward(const BrushUniforms *h_uniforms, const Brus
     mark_bwd(s, 2);
     // GatherGrads + ProjectBackwards fused, dense outputs written once (render.rs:534-594)
     BRUSH_HIP_CHECK(launch_project_backward(vp, means, log_scales, quats, raw_opacity, aux.compact_from_global_gid,
-                                            ws.v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac, s));
+                                            ws.v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac, adam, s));
     mark_bwd(s, 3);
     return BRUSH_OK;
+}
+
+extern "C" int brush_render_backward(const BrushUniforms *h_uniforms, const BrushAux *h_aux, const float *means,
+                                     const float *log_scales, const float *quats, const float *raw_opacity,
+                                     uint32_t n, const float *out_img, const float *v_out, float *v_means,
+                                     float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
+                                     void *workspace, size_t workspace_bytes, brush_stream_t stream) {
+    return render_backward_impl(h_uniforms, h_aux, means, log_scales, quats, raw_opacity, n, out_img, v_out, v_means,
+                                v_xy, v_scales, v_quats, v_sh, v_opac, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int brush_render_backward_adam(const BrushUniforms *h_uniforms, const BrushAux *h_aux,
+                                          const BrushAdamConfig *cfg, float *means, float *log_scales,
+                                          const float *quats_fed, float *rotation, float *raw_opacity, float *sh,
+                                          uint32_t n, const float *out_img, const float *v_out, float *v_xy,
+                                          float *moment1, float *moment2, void *workspace, size_t workspace_bytes,
+                                          brush_stream_t stream) {
+    if (!cfg || cfg->time == 0 || !h_uniforms || h_uniforms->sh_degree > 4) return BRUSH_ERR_INVALID_ARG;
+    if (n > 0 && (!rotation || !sh || !moment1 || !moment2)) return BRUSH_ERR_INVALID_ARG;
+    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!aligned(rotation) || !aligned(quats_fed)) return BRUSH_ERR_INVALID_ARG;
+    AdamFuse af{};
+    af.means = means, af.log_scales = log_scales, af.rotation = rotation, af.raw_opac = raw_opacity, af.sh = sh;
+    af.m1 = moment1, af.m2 = moment2;
+    af.lr[0] = cfg->lr_mean, af.lr[1] = cfg->lr_scale, af.lr[2] = cfg->lr_rotation, af.lr[3] = cfg->lr_opac;
+    af.lr[4] = cfg->lr_coeffs_dc;
+    af.sh_lerp = cfg->sh_rest_lerp, af.beta1 = cfg->beta1, af.beta2 = cfg->beta2, af.eps = cfg->epsilon;
+    af.bc1 = 1.0f - powf(cfg->beta1, (float)cfg->time);
+    af.bc2 = 1.0f - powf(cfg->beta2, (float)cfg->time);
+    af.quat_vjp = cfg->rotation_grad_wrt_normalized;
+    af.vec_ok = (n % 4 == 0) && aligned(means) && aligned(log_scales) && aligned(sh) && aligned(moment1) &&
+                aligned(moment2);
+    return render_backward_impl(h_uniforms, h_aux, means, log_scales, quats_fed, raw_opacity, n, out_img, v_out,
+                                nullptr, v_xy, nullptr, nullptr, nullptr, nullptr, &af, workspace, workspace_bytes,
+                                stream);
 }
 
 // ---- opt-in stage timing ------------------------------------------------------------------

@@ -7,7 +7,8 @@ parameter groups and the higher-order-SH learning-rate lerp (train.rs:318-359).
 
 The reference builds the loss and the optimizer from Burn tensor ops; here they are the fused HIP
 entry points of include/brush_hip.h (brush_l1_ssim_loss, brush_adam_step, brush_refine_stats) called
-straight on the op's forward/backward, so one iteration is ≈40 kernel launches and no autograd graph.
+straight on the op's forward/backward, so one iteration is ≈40 kernel launches and no autograd graph;
+with a single view the optimizer step runs inside the backward's last kernel (brush_render_backward_adam).
 """
 from __future__ import annotations
 
@@ -110,6 +111,7 @@ class SplatTrainer:
         self.moment1 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
         self.moment2 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
         self.opt_time = 0  # Adam's per-parameter step count (reset with the optimizer at refinement)
+        self.fused_backward = True  # single view: brush_render_backward_adam instead of backward + brush_adam_step
         self.last_refine: Optional[RefineStats] = None
         self.rng = torch.Generator(device=dev)
         self.rng.manual_seed(self.config.seed)
@@ -208,37 +210,55 @@ class SplatTrainer:
             _lib.check(l.brush_normalize_quats(quats.data_ptr(), norm_rot.data_ptr(), n, stream), "brush_normalize_quats")
         pred, aux, u = R._forward_impl(camera, (w, h), means, log_scales, norm_rot, sh, raw_opac, False, None)
         loss, v_pred = l1_ssim_loss(pred, gt_image, c.ssim_weight, c.ssim_window_size, 1.0 / batch_views)
-        grads, block = R._backward_impl(u, aux, means, log_scales, norm_rot, raw_opac, ncoef, pred, v_pred)
-        if grad_sync is not None:  # view-sharded data parallelism: sum the per-view gradients
-            grad_sync(block, aux)
-
         do_refine = self.iter < c.max_refine_step and self.iter >= c.warmup_steps and self.iter % c.refine_every == 1
         pre_step = None
         if do_refine:  # refinement clones / splits the parameters *before* the optimizer step (train.rs:361-372)
             pre_step = {"means": means.clone(), "rotation": quats.clone(), "sh": sh.clone(), "opac": raw_opac.clone(),
                         "scales": log_scales.clone()}
+        cfg = _lib.BrushAdamConfig(self._lr_mean(scene_extent), c.lr_scale, c.lr_rotation, c.lr_opac,
+                                   c.lr_coeffs_dc, 1.0 / c.lr_coeffs_sh_scale, 0.9, 0.999, 1e-15, self.opt_time + 1, 1)
+        want_stats = self.iter > c.warmup_steps  # housekeeping, train.rs:284-316
         with torch.cuda.device(means.device):
-            if self.iter > c.warmup_steps:  # housekeeping, train.rs:284-316
-                v_xy = grads["v_xy"]
-                if torch.distributed.is_available() and torch.distributed.is_initialized() and batch_views > 1:
-                    from .dist import densification_stats
-                    stats = densification_stats(v_xy, aux, (w, h))
-                    allreduce_densification_stats(stats)
-                    self.grad_2d_accum += stats[0]
-                    self.xy_grad_counts += stats[1]
-                else:
-                    s = aux._as_struct()
-                    _lib.check(l.brush_refine_stats(C.byref(s), v_xy.data_ptr(), n, w, h, self.grad_2d_accum.data_ptr(),
+            if grad_sync is None and self.fused_backward:
+                # single view: gradients go straight through the optimizer inside the backward kernel
+                nbytes = C.c_size_t()
+                _lib.check(l.brush_bwd_workspace_size(n, w, h, int(u.sh_degree), C.byref(nbytes)), "brush_bwd_workspace_size")
+                ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=means.device)
+                v_xy = torch.empty((max(n, 1), 2), dtype=torch.float32, device=means.device)
+                s_aux = aux._as_struct()
+                _lib.check(l.brush_render_backward_adam(C.byref(u), C.byref(s_aux), C.byref(cfg), means.data_ptr(),
+                                                        log_scales.data_ptr(), norm_rot.data_ptr(), quats.data_ptr(),
+                                                        raw_opac.data_ptr(), sh.data_ptr(), n, pred.data_ptr(),
+                                                        v_pred.data_ptr(), v_xy.data_ptr(), self.moment1.data_ptr(),
+                                                        self.moment2.data_ptr(), ws.data_ptr(), nbytes.value, stream),
+                           "brush_render_backward_adam")
+                if want_stats:
+                    _lib.check(l.brush_refine_stats(C.byref(s_aux), v_xy.data_ptr(), n, w, h, self.grad_2d_accum.data_ptr(),
                                                     self.xy_grad_counts.data_ptr(), stream), "brush_refine_stats")
-            cfg = _lib.BrushAdamConfig(self._lr_mean(scene_extent), c.lr_scale, c.lr_rotation, c.lr_opac,
-                                       c.lr_coeffs_dc, 1.0 / c.lr_coeffs_sh_scale, 0.9, 0.999, 1e-15, self.opt_time + 1, 1)
-            _lib.check(l.brush_adam_step(C.byref(cfg), n, R.sh_degree_from_coeffs(ncoef), means.data_ptr(),
-                                         log_scales.data_ptr(), quats.data_ptr(), raw_opac.data_ptr(), sh.data_ptr(),
-                                         grads["v_means"].data_ptr(), grads["v_scales"].data_ptr(),
-                                         grads["v_quats"].data_ptr(), grads["v_opac"].data_ptr(),
-                                         grads["v_sh"].data_ptr(), self.moment1.data_ptr(), self.moment2.data_ptr(),
-                                         stream),
-                       "brush_adam_step")
+            else:
+                grads, block = R._backward_impl(u, aux, means, log_scales, norm_rot, raw_opac, ncoef, pred, v_pred)
+                if grad_sync is not None:  # view-sharded data parallelism: sum the per-view gradients
+                    grad_sync(block, aux)
+                if want_stats:
+                    v_xy = grads["v_xy"]
+                    if torch.distributed.is_available() and torch.distributed.is_initialized() and batch_views > 1:
+                        from .dist import densification_stats
+                        stats = densification_stats(v_xy, aux, (w, h))
+                        allreduce_densification_stats(stats)
+                        self.grad_2d_accum += stats[0]
+                        self.xy_grad_counts += stats[1]
+                    else:
+                        s_aux = aux._as_struct()
+                        _lib.check(l.brush_refine_stats(C.byref(s_aux), v_xy.data_ptr(), n, w, h,
+                                                        self.grad_2d_accum.data_ptr(), self.xy_grad_counts.data_ptr(),
+                                                        stream), "brush_refine_stats")
+                _lib.check(l.brush_adam_step(C.byref(cfg), n, R.sh_degree_from_coeffs(ncoef), means.data_ptr(),
+                                             log_scales.data_ptr(), quats.data_ptr(), raw_opac.data_ptr(), sh.data_ptr(),
+                                             grads["v_means"].data_ptr(), grads["v_scales"].data_ptr(),
+                                             grads["v_quats"].data_ptr(), grads["v_opac"].data_ptr(),
+                                             grads["v_sh"].data_ptr(), self.moment1.data_ptr(), self.moment2.data_ptr(),
+                                             stream),
+                           "brush_adam_step")
         self.opt_time += 1
         self.last_refine = self.refine_splats(splats, pre_step) if do_refine else None
         self.iter += 1
