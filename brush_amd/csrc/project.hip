@@ -225,45 +225,41 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
     }
     for (uint32_t i = gt; i < num_bin_words; i += gridDim.x * kThreads) tile_bins[i] = 0;  // render.rs:241-244
 
-    // kCullPerThread independent splats per lane (round r covers 256 consecutive splats).  All 44
-    // bytes of the four splats are requested up front with unconditional (clamped) loads: one memory
-    // phase per wave; the culls below only decide how much arithmetic follows.
-    float mean_r[kCullPerThread][3], lsv_r[kCullPerThread][3], opac_raw[kCullPerThread];
-    float4 q4_r[kCullPerThread];
+    // Phase A — every splat of the wave's 4 x 64 (round r covers 256 consecutive splats): the two cheap
+    // rejections (behind the camera :32, and a conservative screen-bounds test that never changes a
+    // decision).  Only ~1 splat in 8 survives them, so the survivors' ids are queued per wave and the
+    // expensive exact projection (Phase B) runs on full waves instead of once per round at 12 % lane
+    // occupancy.  The loads of all four rounds are issued up front (one memory phase per wave).
+    float mean_r[kCullPerThread][3], smax_r[kCullPerThread];
     const uint32_t last = vp.total_splats ? vp.total_splats - 1 : 0;
 #pragma unroll
     for (uint32_t r = 0; r < kCullPerThread; r++) {
         const size_t g = min(blockIdx.x * kCullBlock + r * kThreads + threadIdx.x, last);
         if (vp.total_splats) {  // uniform: an empty cloud has no row 0 to clamp to
 #pragma unroll
-            for (int k = 0; k < 3; k++) mean_r[r][k] = means[g * 3 + k], lsv_r[r][k] = log_scales[g * 3 + k];
-            q4_r[r] = reinterpret_cast<const float4 *>(quats)[g];
-            opac_raw[r] = raw_opac[g];
+            for (int k = 0; k < 3; k++) mean_r[r][k] = means[g * 3 + k];
+            smax_r[r] = fmaxf(log_scales[g * 3], fmaxf(log_scales[g * 3 + 1], log_scales[g * 3 + 2]));
         } else {
-#pragma unroll
-            for (int k = 0; k < 3; k++) mean_r[r][k] = 0.0f, lsv_r[r][k] = 0.0f;
-            q4_r[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            opac_raw[r] = 0.0f;
+            mean_r[r][0] = mean_r[r][1] = mean_r[r][2] = 0.0f;
+            smax_r[r] = 0.0f;
         }
     }
-    uint32_t block_visible = 0;
+    uint32_t n_cand = 0;
+    uint32_t *list = vis_list[threadIdx.x / kWave];
 #pragma unroll
     for (uint32_t r = 0; r < kCullPerThread; r++) {
         const uint32_t g = blockIdx.x * kCullBlock + r * kThreads + threadIdx.x;
-        bool visible = false;
-        float depth = 0.0f;
+        bool maybe = false;
         if (g < vp.total_splats) {
             const float mean[3] = {mean_r[r][0], mean_r[r][1], mean_r[r][2]};
-            const float lsv[3] = {lsv_r[r][0], lsv_r[r][1], lsv_r[r][2]};
-            const float4 q4 = q4_r[r];
             float p_view[3];
             to_view(vp, mean, p_view);
-            bool maybe = p_view[2] > 0.01f;  // :32
+            maybe = p_view[2] > 0.01f;  // :32
             if (maybe) {
-                // Conservative early reject (never changes a decision): radius <= 3*sqrt(lambda_max + quirk
-                // slack) + 1 with lambda_max(cov2d) <= trace <= s_max^2 * cull_k / z^2 + 0.6; if even that
-                // radius leaves the tile bbox empty, the exact test below (:54-62) would reject as well.
-                const float smax = det_expf(fmaxf(lsv[0], fmaxf(lsv[1], lsv[2]))) * 1.001f;
+                // radius <= 3*sqrt(lambda_max + quirk slack) + 1 with lambda_max(cov2d) <= trace <=
+                // s_max^2 * cull_k / z^2 + 0.6; if even that radius leaves the tile bbox empty, the exact
+                // test (:54-62) would reject as well.
+                const float smax = det_expf(smax_r[r]) * 1.001f;
                 const float rz = 1.0f / p_view[2];
                 const float lam = smax * smax * vp.cull_k * rz * rz + 1.0f;
                 const float rb = 3.0f * sqrtf(lam) + 2.0f;
@@ -272,49 +268,54 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                 const float wpx = (float)(vp.tile_bounds[0] * kTileWidth), hpx = (float)(vp.tile_bounds[1] * kTileWidth);
                 if (cxp + rb < -1.0f || cxp - rb > wpx + 1.0f || cyp + rb < -1.0f || cyp - rb > hpx + 1.0f) maybe = false;
             }
-
-            if (maybe) {
-                const float scale[3] = {det_expf(lsv[0]), det_expf(lsv[1]), det_expf(lsv[2])};
-                const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-                float cov2d[3];
-                calc_cov2d(vp, p_view, scale, quat, cov2d);
-                const float det = cov2d[0] * cov2d[2] - cov2d[1] * cov2d[1];
-                if (!(det == 0.0f)) {  // :43
-                    float conic[3], xy[2];
-                    cov_to_conic(cov2d, conic);
-                    project_pix(vp, p_view, xy);
-                    const uint32_t radius = radius_from_conic(conic);
-                    uint32_t bb[4];
-                    get_tile_bbox(xy, radius, vp.tile_bounds, bb);
-                    if ((bb[2] - bb[0]) != 0u && (bb[3] - bb[1]) != 0u) {  // :60
-                        visible = true;
-                        depth = p_view[2];
-                        const float opac = det_sigmoid(opac_raw[r]);
-                        float4 *row = proj_global + (size_t)g * 3;
-                        row[0] = make_float4(xy[0], xy[1], conic[0], conic[1]);
-                        row[1] = make_float4(conic[2], opac, 0.0f, 0.0f);
-                    }
-                }
-            }
-            key_all[g] = visible ? __float_as_uint(depth) : kInvalid;
+            if (!maybe) key_all[g] = kInvalid;
             compact_from_global[g] = kInvalid;
         }
-        // the few lanes that passed (~10 %) queue their id; the SH evaluation below then runs on full
-        // waves instead of once per round at 10 % lane occupancy
-        const uint64_t bal = __ballot(visible);
-        if (visible) vis_list[threadIdx.x / kWave][block_visible + __popcll(bal & lanemask_lt())] = g;
-        block_visible += __popcll(bal);
+        const uint64_t bal = __ballot(maybe);
+        if (maybe) list[n_cand + __popcll(bal & lanemask_lt())] = g;
+        n_cand += __popcll(bal);
     }
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t base = 0; base < block_visible; base += kWave) {  // wave-uniform
+
+    // Phase B — exact cull (project_forward.wgsl:36-66) and, for the splats that pass, the whole
+    // ProjectedSplat record (project_visible.wgsl:163-258).
+    uint32_t block_visible = 0;
+    for (uint32_t base = 0; base < n_cand; base += kWave) {  // wave-uniform
         const uint32_t i = base + lane_id();
-        if (i < block_visible) {
-            const uint32_t g = vis_list[threadIdx.x / kWave][i];
+        bool visible = false;
+        if (i < n_cand) {
+            const uint32_t g = list[i];
             const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
-            float rgb[3];
-            sh_colour<DEG>(vp, mean, sh_coeffs + (size_t)g * ((DEG + 1) * (DEG + 1)) * 3, rgb);
-            proj_global[(size_t)g * 3 + 2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+            const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
+                                    det_expf(log_scales[(size_t)g * 3 + 2])};
+            const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
+            const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+            const float ro = raw_opac[g];
+            const float *sh = sh_coeffs + (size_t)g * ((DEG + 1) * (DEG + 1)) * 3;
+            float p_view[3], cov2d[3];
+            to_view(vp, mean, p_view);
+            calc_cov2d(vp, p_view, scale, quat, cov2d);
+            const float det = cov2d[0] * cov2d[2] - cov2d[1] * cov2d[1];
+            if (!(det == 0.0f)) {  // :43
+                float conic[3], xy[2];
+                cov_to_conic(cov2d, conic);
+                project_pix(vp, p_view, xy);
+                const uint32_t radius = radius_from_conic(conic);
+                uint32_t bb[4];
+                get_tile_bbox(xy, radius, vp.tile_bounds, bb);
+                if ((bb[2] - bb[0]) != 0u && (bb[3] - bb[1]) != 0u) {  // :60
+                    visible = true;
+                    float rgb[3];
+                    sh_colour<DEG>(vp, mean, sh, rgb);
+                    float4 *row = proj_global + (size_t)g * 3;
+                    row[0] = make_float4(xy[0], xy[1], conic[0], conic[1]);
+                    row[1] = make_float4(conic[2], det_sigmoid(ro), 0.0f, 0.0f);
+                    row[2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+                }
+            }
+            key_all[g] = visible ? __float_as_uint(p_view[2]) : kInvalid;
         }
+        block_visible += __popcll(__ballot(visible));
     }
     if (lane_id() == 0) wave_cnt[threadIdx.x / kWave] = block_visible;
     __syncthreads();
