@@ -106,17 +106,39 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
     constexpr uint32_t kRow = ncoef * 3;                 // floats per v_sh row
     constexpr uint32_t kRowPad = kRow | 1u;              // odd LDS row stride: conflict-free column access
-    constexpr uint32_t kStageFloats = (kWave * kRowPad > 512u ? kWave * kRowPad : 512u);
+    constexpr uint32_t kRes = 16 + ncoef;  // per-splat VJP results: mean3 scale3 quat4 opac xy2 vcol3 | Y[ncoef]
+    constexpr uint32_t kStageA = (kWave * kRowPad > 512u ? kWave * kRowPad : 512u);
+    constexpr uint32_t kStageFloats = kStageA > kWave * kRes ? kStageA : kWave * kRes;
     __shared__ float stage_all[kThreads / kWave][kStageFloats];
     const uint32_t wv = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     float *stage = stage_all[wv];
     const uint32_t n = vp.total_splats;
     const uint32_t g0 = blockIdx.x * kThreads + wv * kWave;  // first splat of this wave
-    if (g0 >= n) return;                                      // wave-uniform
-    const uint32_t g = g0 + lane;
-    const bool in_range = g < n;
-    const uint32_t c = in_range ? compact_from_global[g] : kInvalid;
+    const uint32_t g_own = g0 + lane;
+    const bool in_range = g_own < n;
+    const uint32_t c_own = in_range ? compact_from_global[g_own] : kInvalid;
+
+    // Only ~10 % of the splats are visible, and the VJP below is ~1500 instructions: the visible
+    // splats of the block's 256 are compacted (ballot + LDS) so the arithmetic runs on nearly full
+    // waves, and the results travel back to the owning lane through LDS (aliasing the store staging).
+    __shared__ uint32_t vis_cnt[kThreads / kWave];
+    __shared__ uint16_t vis_list[kThreads];
+    static_assert(kThreads * kRes <= (kThreads / kWave) * kStageFloats, "result rows must fit the staging buffer");
+    float *res = &stage_all[0][0];
+    {
+        const uint64_t bal = __ballot(c_own != kInvalid);
+        if (lane == 0) vis_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        uint32_t pos = __popcll(bal & lanemask_lt());
+        for (uint32_t w2 = 0; w2 < wv; w2++) pos += vis_cnt[w2];
+        if (c_own != kInvalid) vis_list[pos] = (uint16_t)threadIdx.x;
+        __syncthreads();
+    }
+    const uint32_t nvis = vis_cnt[0] + vis_cnt[1] + vis_cnt[2] + vis_cnt[3];
+    const uint32_t li = threadIdx.x < nvis ? vis_list[threadIdx.x] : 0u;
+    const uint32_t g = blockIdx.x * kThreads + li;
+    const uint32_t c = threadIdx.x < nvis ? compact_from_global[g] : kInvalid;
 
     float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_quat[4] = {0.f, 0.f, 0.f, 0.f};
     float o_xy[2] = {0.f, 0.f}, o_opac = 0.f;
@@ -228,18 +250,40 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
         }
         const Mat3 v_R = mul(v_M, S);
         quat_to_rotmat_vjp(quat, v_R, o_quat);
-    }
 
+        float *r = res + li * kRes;  // hand the results to the lane that owns splat `li`
+        r[0] = o_mean[0], r[1] = o_mean[1], r[2] = o_mean[2];
+        r[3] = o_scale[0], r[4] = o_scale[1], r[5] = o_scale[2];
+        r[6] = o_quat[0], r[7] = o_quat[1], r[8] = o_quat[2], r[9] = o_quat[3];
+        r[10] = o_opac, r[11] = o_xy[0], r[12] = o_xy[1];
+        r[13] = vcol[0], r[14] = vcol[1], r[15] = vcol[2];
+#pragma unroll
+        for (uint32_t k = 0; k < ncoef; k++) r[16 + k] = Y[k];
+    }
+    __syncthreads();
+    {
+        const float *r = res + threadIdx.x * kRes;
+        const bool vis = c_own != kInvalid;
+        o_mean[0] = vis ? r[0] : 0.f, o_mean[1] = vis ? r[1] : 0.f, o_mean[2] = vis ? r[2] : 0.f;
+        o_scale[0] = vis ? r[3] : 0.f, o_scale[1] = vis ? r[4] : 0.f, o_scale[2] = vis ? r[5] : 0.f;
+        o_quat[0] = vis ? r[6] : 0.f, o_quat[1] = vis ? r[7] : 0.f, o_quat[2] = vis ? r[8] : 0.f, o_quat[3] = vis ? r[9] : 0.f;
+        o_opac = vis ? r[10] : 0.f, o_xy[0] = vis ? r[11] : 0.f, o_xy[1] = vis ? r[12] : 0.f;
+        vcol[0] = vis ? r[13] : 0.f, vcol[1] = vis ? r[14] : 0.f, vcol[2] = vis ? r[15] : 0.f;
+#pragma unroll
+        for (uint32_t k = 0; k < ncoef; k++) Y[k] = vis ? r[16 + k] : 0.f;
+    }
+    __syncthreads();  // `res` aliases the store staging below
+    if (g0 >= n) return;  // wave-uniform; past the last barrier
     const uint32_t rows = min(kWave, n - g0);  // rows this wave owns (64 except at the tail)
     const size_t nn = n;
     if (in_range) {
-        reinterpret_cast<float2 *>(v_xy)[g] = make_float2(o_xy[0], o_xy[1]);
+        reinterpret_cast<float2 *>(v_xy)[g_own] = make_float2(o_xy[0], o_xy[1]);
         if (!ADAM) {
-            reinterpret_cast<float4 *>(v_quats)[g] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
-            v_opac[g] = o_opac;
+            reinterpret_cast<float4 *>(v_quats)[g_own] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
+            v_opac[g_own] = o_opac;
         } else {
             // rotation: the op was fed rot/|rot| (gaussian_splats.rs:174-175); chain v_q to the raw parameter
-            float4 r = reinterpret_cast<const float4 *>(af.rotation)[g];
+            float4 r = reinterpret_cast<const float4 *>(af.rotation)[g_own];
             float4 gq = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
             if (af.quat_vjp) {
                 const float s2 = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
@@ -248,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
                 gq = make_float4(gq.x * inv_s - r.x * dot, gq.y * inv_s - r.y * dot, gq.z * inv_s - r.z * dot,
                                  gq.w * inv_s - r.w * dot);
             }
-            const size_t e = 6 * nn + (size_t)g * 4;
+            const size_t e = 6 * nn + (size_t)g_own * 4;
             if (af.vec_ok) {
                 r = adam_elem4(af, e, gq, r, af.lr[2]);
             } else {
@@ -257,8 +301,8 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
                 r.z = adam_elem(af, e + 2, gq.z, r.z, af.lr[2]);
                 r.w = adam_elem(af, e + 3, gq.w, r.w, af.lr[2]);
             }
-            reinterpret_cast<float4 *>(af.rotation)[g] = r;
-            af.raw_opac[g] = adam_elem(af, 10 * nn + g, o_opac, af.raw_opac[g], af.lr[3]);
+            reinterpret_cast<float4 *>(af.rotation)[g_own] = r;
+            af.raw_opac[g_own] = adam_elem(af, 10 * nn + g_own, o_opac, af.raw_opac[g_own], af.lr[3]);
         }
     }
 
