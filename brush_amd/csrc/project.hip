@@ -38,20 +38,24 @@ constexpr uint32_t kCullBlock = kThreads * kCullPerThread;  // splats per cull w
 //     the bbox areas), every lane tests one candidate per step after finding its owner splat with
 //     a 6-step shuffle binary search, and each owner harvests its hit bits from the step's ballot
 //     (count + 64-bit hit mask).  All lanes do useful tests regardless of how uneven the areas are;
-//   * larger ones are cut into chunks of kChunkTiles tiles and queued as (splat, chunk) work items
+//   * larger ones are cut into chunks of kChunkTiles (64) tiles and queued as (splat, chunk) work items
 //     (one atomicAdd per wave reserves consecutive slots).  A second launch consumes the queue
-//     one wave64 per item, 64 tiles per step, so a whole-screen splat is spread over dozens of
-//     waves.
+//     4 or 16 items per wave (the lanes fetch the items' geometry in one memory phase, then one
+//     64-tile step per item), so a whole-screen splat is spread over many waves.
 // If the queue is full the lane falls back to walking its bbox inline (slow, still correct).
 // The hit masks are kept so that the emission pass never repeats the exact test.
 constexpr uint32_t kSmallArea = 16;
-constexpr uint32_t kChunkTiles = 256;
+constexpr uint32_t kChunkTiles = 64;   // one 64-bit hit mask per queue item
+constexpr uint32_t kWalkGroupMax = 16;  // queue items a consumer wave takes at a time when the queue is long
+// Few items: small groups (more waves, shorter serial chains); many items: amortise the memory phase.
+__device__ __forceinline__ uint32_t walk_group(uint32_t n_items) { return n_items <= 16384u ? 4u : kWalkGroupMax; }
 
 struct WalkQueue {
     uint32_t *counter;      // [1] items reserved so far (zeroed by the cull kernel)
     uint2 *items;           // [capacity] (compact gid, chunk index)
-    uint32_t *chunk_count;  // [capacity] tiles hit inside the chunk (written by the count pass)
-    uint64_t *chunk_mask;   // [capacity][4] hit bitmask of the chunk's 256 tiles (count pass -> emit pass)
+    uint32_t *chunk_count;  // [capacity] tiles hit inside the chunks up to and including this one, counted from the
+                            //     start of the item's group of walk_group(n) items (group-local inclusive prefix)
+    uint64_t *chunk_mask;   // [capacity] hit bitmask of the chunk's 64 tiles (count pass -> emit pass)
     uint32_t *slot_of;      // [N] queued splat: first item slot (< 2^31); inline splat: kInlineFlag
                             //     (hit mask in inline_mask) or kInlineRetest
     uint64_t *inline_mask;  // [N] hit mask of an inline splat's <= 64 bbox tiles (row-major)
@@ -73,8 +77,10 @@ __device__ __forceinline__ uint32_t walk_inline_count(const uint32_t bb[4], cons
 // Wave-flattened walk of the wave's small bboxes.  `area` = this lane's bbox tile count (0 if the
 // lane has no small bbox).  Must be called by all 64 lanes.  Returns this lane's hit count and
 // its row-major hit mask.
+// `first` = row-major index (inside the lane's bbox) of the lane's first candidate: 0 for a whole
+// small bbox, k * kChunkTiles for chunk k of a queued one.
 __device__ __forceinline__ void walk_flat(uint32_t area, const uint32_t bb[4], const TileTest &tt, const float xy[2],
-                                          uint32_t &cnt, uint64_t &mask) {
+                                          uint32_t first, uint32_t &cnt, uint64_t &mask) {
     const uint32_t lane = lane_id();
     const uint32_t bw = bb[2] - bb[0];
     cnt = 0;
@@ -97,10 +103,10 @@ __device__ __forceinline__ void walk_flat(uint32_t area, const uint32_t bb[4], c
         ot.any = __shfl((int)tt.any, own, 64) != 0;
         const float oxy[2] = {__shfl(xy[0], own, 64), __shfl(xy[1], own, 64)};
         const uint32_t ob0 = __shfl(bb[0], own, 64), ob1 = __shfl(bb[1], own, 64);
-        const uint32_t obw = __shfl(bw, own, 64), oexcl = __shfl(excl, own, 64);
+        const uint32_t obw = __shfl(bw, own, 64), oexcl = __shfl(excl, own, 64), ofirst = __shfl(first, own, 64);
         bool hit = false;
         if (j < total) {
-            const uint32_t li = j - oexcl;
+            const uint32_t li = ofirst + (j - oexcl);
             hit = can_be_visible(ot, ob0 + li % obw, ob1 + li / obw, oxy);
         }
         const uint64_t bal = __ballot(hit);
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
         const bool small = active && bbox_tiles <= kSmallArea;
         uint32_t flat_cnt;
         uint64_t flat_mask;
-        walk_flat(small ? bbox_tiles : 0u, bb, tt, xy, flat_cnt, flat_mask);
+        walk_flat(small ? bbox_tiles : 0u, bb, tt, xy, 0u, flat_cnt, flat_mask);
         if (small) {
             area = flat_cnt;
             slot = kInlineFlag;
@@ -496,30 +502,61 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
     }
 }
 
-// Second half of the tile count: one wave64 per queued (splat, chunk) item.
+__device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src_lane) {  // src_lane wave-uniform
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane);
+}
+__device__ __forceinline__ float bcastf(float v, uint32_t src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)src_lane));
+}
+
+// Second half of the tile count.  A wave takes walk_group(n) consecutive queue items: those lanes fetch the
+// items and their splats' geometry in ONE memory phase, then the wave spends one step per item with
+// the 64 lanes on the chunk's 64 tiles (geometry broadcast with v_readlane).  Besides the per-splat
+// total (atomicAdd into tiles_hit) it records each item's hit mask and the running hit count inside
+// the group, from which the emit pass derives every item's output offset without a scan.
 __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const float *__restrict__ projected,
                                                          WalkQueue q, uint32_t *__restrict__ tiles_hit) {
     const uint32_t n_items = min(*q.counter, q.capacity);
+    const uint32_t G = walk_group(n_items);
+    const uint32_t n_groups = (n_items + G - 1) / G;
     const uint32_t lane = lane_id();
     const uint32_t waves = gridDim.x * (kThreads / kWave);
-    for (uint32_t it = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; it < n_items; it += waves) {
-        const uint2 item = q.items[it];
-        if (item.x == kInvalid) continue;  // hole left by a reservation that straddled the capacity
-        const SplatWalk s = load_walk(vp, projected, item.x);
-        const uint32_t lo = item.y * kChunkTiles, hi = min(s.area, lo + kChunkTiles);
-        uint32_t cnt = 0;
-        uint64_t my_mask = 0;  // lane k keeps the ballot of step k
-        for (uint32_t i0 = lo, step = 0; i0 < hi; i0 += kWave, step++) {
-            const uint32_t i = i0 + lane;
-            const bool hit = i < hi && can_be_visible(s.tt, s.b0 + i % s.bw, s.b1 + i / s.bw, s.xy);
+    for (uint32_t grp = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; grp < n_groups; grp += waves) {
+        const uint32_t it = grp * G + lane;
+        const bool mine = lane < G && it < n_items;
+        uint2 item = make_uint2(kInvalid, 0u);
+        if (mine) item = q.items[it];
+        const bool valid = mine && item.x != kInvalid;  // hole left by a reservation that straddled the capacity
+        SplatWalk s;
+        s.xy[0] = s.xy[1] = 0.f;
+        s.tt.q[0] = s.tt.q[1] = s.tt.q[2] = 0.f;
+        s.tt.any = false;
+        s.b0 = s.b1 = s.area = 0u;
+        s.bw = 1u;
+        if (valid) s = load_walk(vp, projected, item.x);
+        const uint32_t first = item.y * kChunkTiles;
+        const uint32_t len = (valid && first < s.area) ? min(s.area - first, kChunkTiles) : 0u;
+        uint32_t my_cnt = 0;
+        uint64_t my_mask = 0;
+        const uint32_t in_group = min(G, n_items - grp * G);
+        for (uint32_t qi = 0; qi < in_group; qi++) {  // wave-uniform
+            const uint32_t qlen = bcast(len, qi);
+            if (qlen == 0) continue;
+            TileTest t;
+            t.q[0] = bcastf(s.tt.q[0], qi), t.q[1] = bcastf(s.tt.q[1], qi), t.q[2] = bcastf(s.tt.q[2], qi);
+            t.any = bcast((uint32_t)s.tt.any, qi) != 0u;
+            const float xy[2] = {bcastf(s.xy[0], qi), bcastf(s.xy[1], qi)};
+            const uint32_t b0 = bcast(s.b0, qi), b1 = bcast(s.b1, qi), bw = bcast(s.bw, qi);
+            const uint32_t i = bcast(first, qi) + lane;
+            const bool hit = lane < qlen && can_be_visible(t, b0 + i % bw, b1 + i / bw, xy);
             const uint64_t bal = __ballot(hit);
-            cnt += __popcll(bal);
-            if (lane == step) my_mask = bal;
+            if (lane == qi) my_mask = bal, my_cnt = __popcll(bal);
         }
-        if (lane < kChunkTiles / kWave) q.chunk_mask[(size_t)it * (kChunkTiles / kWave) + lane] = my_mask;
-        if (lane == 0) {
-            q.chunk_count[it] = cnt;
-            if (cnt) atomicAdd(&tiles_hit[item.x], cnt);
+        const uint32_t pre = wave_inclusive_scan(lane < G ? my_cnt : 0u);
+        if (mine) {
+            q.chunk_count[it] = pre;
+            q.chunk_mask[it] = my_mask;
+            if (my_cnt) atomicAdd(&tiles_hit[item.x], my_cnt);
         }
     }
 }
@@ -563,44 +600,68 @@ __global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, cons
     }
 }
 
-// One wave64 per queued item; the item's first output slot is the splat's exclusive prefix plus
-// the hit counts of the splat's earlier chunks (its items occupy consecutive queue slots).
+// Emission for the queued splats, walk_group(n) items per wave like the count pass.  Item (c, k) writes
+// after the k earlier chunks of its splat, which are the k items before it in the queue: their hit
+// total is a difference of the group-local running counts (at most 128 / G + 2 loads), so
+// the entries of a splat land in [cum[c-1], cum[c]) in row-major bbox order, as an inline walk
+// writes them.
 __global__ __launch_bounds__(kThreads) void k_walk_emit(ViewParams vp, const float *__restrict__ projected,
                                                         const uint32_t *__restrict__ cum_tiles_hit, uint32_t cap,
                                                         uint32_t *__restrict__ tile_ids, uint32_t *__restrict__ gids,
                                                         WalkQueue q) {
     const uint32_t n_items = min(*q.counter, q.capacity);
+    const uint32_t G = walk_group(n_items);
+    const uint32_t n_groups = (n_items + G - 1) / G;
     const uint32_t lane = lane_id();
     const uint64_t lt = lanemask_lt();
     const uint32_t waves = gridDim.x * (kThreads / kWave);
-    for (uint32_t it = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; it < n_items; it += waves) {
-        const uint2 item = q.items[it];
-        if (item.x == kInvalid) continue;
-        const uint32_t c = item.x, k = item.y;
-        uint32_t before = 0;
-        for (uint32_t j = lane; j < k; j += kWave) before += q.chunk_count[it - k + j];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
-        uint32_t run = (c > 0 ? cum_tiles_hit[c - 1] : 0u) + before;
-        // bbox geometry only (no tile tests): replay the recorded hit masks in order
-        const float *pp = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
-        const float xy[2] = {pp[0], pp[1]};
-        const float conic[3] = {pp[2], pp[3], pp[4]};
-        uint32_t bb[4];
-        get_tile_bbox(xy, radius_from_conic(conic), vp.tile_bounds, bb);
-        const uint32_t bw = bb[2] - bb[0];
-        const uint32_t area = bw * (bb[3] - bb[1]);
-        const uint32_t lo = k * kChunkTiles, hi = min(area, lo + kChunkTiles);
-        for (uint32_t i0 = lo, step = 0; i0 < hi; i0 += kWave, step++) {
-            const uint32_t i = i0 + lane;
-            const uint64_t bal = q.chunk_mask[(size_t)it * (kChunkTiles / kWave) + step];
-            const bool hit = (bal >> lane) & 1ull;
-            const uint32_t pos = run + __popcll(bal & lt);
-            if (hit && pos < cap) {
-                tile_ids[pos] = (bb[0] + i % bw) + (bb[1] + i / bw) * vp.tile_bounds[0];
-                gids[pos] = c;
+    for (uint32_t grp = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; grp < n_groups; grp += waves) {
+        const uint32_t g_first = grp * G;
+        const uint32_t it = g_first + lane;
+        const bool mine = lane < G && it < n_items;
+        uint2 item = make_uint2(kInvalid, 0u);
+        if (mine) item = q.items[it];
+        const bool valid = mine && item.x != kInvalid;
+        uint32_t b0 = 0, b1 = 0, bw = 1, base = 0, first = 0;
+        uint64_t mask = 0;
+        if (valid) {
+            const uint32_t c = item.x, k = item.y;
+            mask = q.chunk_mask[it];
+            // hits of the k preceding items = [it - k, it): whole groups by their last running count,
+            // the two partial groups by differences
+            uint32_t before = 0;
+            const uint32_t lo = it - k;  // first item of this splat
+            if (lo >= g_first) {         // all in this group
+                before = (lane > 0 ? q.chunk_count[it - 1] : 0u) - (lo > g_first ? q.chunk_count[lo - 1] : 0u);
+            } else {
+                before = lane > 0 ? q.chunk_count[it - 1] : 0u;                       // this group's part
+                const uint32_t lo_grp = lo / G;
+                for (uint32_t g2 = lo_grp + 1; g2 < grp; g2++) before += q.chunk_count[g2 * G + G - 1];
+                const uint32_t lg_last = lo_grp * G + G - 1;                             // the splat's first group
+                before += q.chunk_count[lg_last] - (lo > lo_grp * G ? q.chunk_count[lo - 1] : 0u);
             }
-            run += __popcll(bal);
+            const float *pp = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
+            const float xy[2] = {pp[0], pp[1]};
+            const float conic[3] = {pp[2], pp[3], pp[4]};
+            uint32_t bb[4];
+            get_tile_bbox(xy, radius_from_conic(conic), vp.tile_bounds, bb);
+            b0 = bb[0], b1 = bb[1], bw = bb[2] - bb[0];
+            first = k * kChunkTiles;
+            base = (c > 0 ? cum_tiles_hit[c - 1] : 0u) + before;
+        }
+        const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+        const uint32_t in_group = min(G, n_items - g_first);
+        for (uint32_t qi = 0; qi < in_group; qi++) {  // wave-uniform
+            const uint64_t bal = ((uint64_t)bcast(mhi, qi) << 32) | bcast(mlo, qi);
+            if (bal == 0ull) continue;
+            const uint32_t qb0 = bcast(b0, qi), qb1 = bcast(b1, qi), qbw = bcast(bw, qi);
+            const uint32_t i = bcast(first, qi) + lane;
+            const uint32_t pos = bcast(base, qi) + __popcll(bal & lt);
+            const uint32_t qc = bcast(item.x, qi);
+            if (((bal >> lane) & 1ull) && pos < cap) {
+                tile_ids[pos] = (qb0 + i % qbw) + (qb1 + i / qbw) * vp.tile_bounds[0];
+                gids[pos] = qc;
+            }
         }
     }
 }
