@@ -563,16 +563,17 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
 
 // ---- MapGaussiansToIntersect ---------------------------------------------------------------
 // map_gaussian_to_intersects.wgsl:10-48: splats walked inline by project_visible emit here inline;
-// queued splats are emitted by k_walk_emit.
-__global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, const float *__restrict__ projected,
-                                                             const uint32_t *__restrict__ cum_tiles_hit,
-                                                             const uint32_t *__restrict__ num_visible,
-                                                             uint32_t cap, uint32_t *__restrict__ tile_ids,
-                                                             uint32_t *__restrict__ gids, WalkQueue q) {
+// queued splats are emitted by the queue role of the same launch.
+__device__ __forceinline__ void map_inline_role(uint32_t bid, uint32_t nblocks, const ViewParams &vp,
+                                                const float *__restrict__ projected,
+                                                const uint32_t *__restrict__ cum_tiles_hit,
+                                                const uint32_t *__restrict__ num_visible, uint32_t cap,
+                                                uint32_t *__restrict__ tile_ids, uint32_t *__restrict__ gids,
+                                                const WalkQueue &q) {
     const uint32_t V = *num_visible;
-    for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < V; c += gridDim.x * kThreads) {
+    for (uint32_t c = bid * kThreads + threadIdx.x; c < V; c += nblocks * kThreads) {
         const uint32_t code = q.slot_of[c];
-        if (!(code & kInlineFlag)) continue;  // queued: emitted by k_walk_emit
+        if (!(code & kInlineFlag)) continue;  // queued: emitted by the queue role
         const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
         const float xy[2] = {p[0], p[1]};
         const float conic[3] = {p[2], p[3], p[4]};
@@ -605,17 +606,18 @@ __global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, cons
 // total is a difference of the group-local running counts (at most 128 / G + 2 loads), so
 // the entries of a splat land in [cum[c-1], cum[c]) in row-major bbox order, as an inline walk
 // writes them.
-__global__ __launch_bounds__(kThreads) void k_walk_emit(ViewParams vp, const float *__restrict__ projected,
-                                                        const uint32_t *__restrict__ cum_tiles_hit, uint32_t cap,
-                                                        uint32_t *__restrict__ tile_ids, uint32_t *__restrict__ gids,
-                                                        WalkQueue q) {
+__device__ __forceinline__ void map_queue_role(uint32_t bid, uint32_t nblocks, const ViewParams &vp,
+                                               const float *__restrict__ projected,
+                                               const uint32_t *__restrict__ cum_tiles_hit, uint32_t cap,
+                                               uint32_t *__restrict__ tile_ids, uint32_t *__restrict__ gids,
+                                               const WalkQueue &q) {
     const uint32_t n_items = min(*q.counter, q.capacity);
     const uint32_t G = walk_group(n_items);
     const uint32_t n_groups = (n_items + G - 1) / G;
     const uint32_t lane = lane_id();
     const uint64_t lt = lanemask_lt();
-    const uint32_t waves = gridDim.x * (kThreads / kWave);
-    for (uint32_t grp = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; grp < n_groups; grp += waves) {
+    const uint32_t waves = nblocks * (kThreads / kWave);
+    for (uint32_t grp = bid * (kThreads / kWave) + threadIdx.x / kWave; grp < n_groups; grp += waves) {
         const uint32_t g_first = grp * G;
         const uint32_t it = g_first + lane;
         const bool mine = lane < G && it < n_items;
@@ -664,6 +666,21 @@ __global__ __launch_bounds__(kThreads) void k_walk_emit(ViewParams vp, const flo
             }
         }
     }
+}
+
+// One launch, two roles: the first `inline_blocks` workgroups emit the inline splats, the rest consume
+// the queue (they write disjoint ranges of the same arrays, so neither waits for the other).
+__global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, const float *__restrict__ projected,
+                                                             const uint32_t *__restrict__ cum_tiles_hit,
+                                                             const uint32_t *__restrict__ num_visible, uint32_t cap,
+                                                             uint32_t *__restrict__ tile_ids,
+                                                             uint32_t *__restrict__ gids, WalkQueue q,
+                                                             uint32_t inline_blocks) {
+    if (blockIdx.x < inline_blocks)
+        map_inline_role(blockIdx.x, inline_blocks, vp, projected, cum_tiles_hit, num_visible, cap, tile_ids, gids, q);
+    else
+        map_queue_role(blockIdx.x - inline_blocks, gridDim.x - inline_blocks, vp, projected, cum_tiles_hit, cap,
+                       tile_ids, gids, q);
 }
 
 // ---- GetTileBinEdges -----------------------------------------------------------------------
@@ -756,10 +773,9 @@ hipError_t launch_map_intersects(const ViewParams &vp, const float *projected, c
                                  const uint32_t *num_visible, uint32_t cap, uint32_t *tile_ids, uint32_t *gids,
                                  const WalkWs &walk, hipStream_t s) {
     const WalkQueue q = make_queue(walk);
-    hipLaunchKernelGGL(k_map_intersects, dim3(stride_grid(vp.total_splats)), dim3(kThreads), 0, s, vp, projected,
-                       cum_tiles_hit, num_visible, cap, tile_ids, gids, q);
-    hipLaunchKernelGGL(k_walk_emit, dim3(1024), dim3(kThreads), 0, s, vp, projected, cum_tiles_hit, cap, tile_ids,
-                       gids, q);
+    const uint32_t inline_blocks = stride_grid(vp.total_splats);
+    hipLaunchKernelGGL(k_map_intersects, dim3(inline_blocks + 1024u), dim3(kThreads), 0, s, vp, projected,
+                       cum_tiles_hit, num_visible, cap, tile_ids, gids, q, inline_blocks);
     return hipGetLastError();
 }
 

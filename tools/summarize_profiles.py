@@ -74,7 +74,7 @@ for k in sorted(pmc):
                                  "hbm_bytes_per_launch": int((2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024)}
 # stage-level sums (the keys bench.py looks up): bytes and VALU instructions per launch of the stage
 STAGES = {"project_cull": ["k_project_cull", "k_cull_scan", "k_compact"], "project_visible": ["k_project_visible", "k_walk_count"],
-          "map_intersects": ["k_map_intersects", "k_walk_emit"], "tile_bins": ["k_tile_bin_edges"],
+          "map_intersects": ["k_map_intersects"], "tile_bins": ["k_tile_bin_edges"],
           "rasterize": ["k_rasterize"], "bwd_zero": ["k_zero_compact_grads"], "rasterize_bwd": ["k_rasterize_backward"],
           "project_bwd": ["k_project_backward"]}
 traffic["valu_insts"] = {}
