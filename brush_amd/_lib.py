@@ -101,7 +101,7 @@ _SYMBOLS = [
      [C.POINTER(BrushAdamConfig), C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("brush_render_backward_adam", C.c_int,
      [C.POINTER(BrushUniforms), C.POINTER(BrushAux), C.POINTER(BrushAdamConfig), _P, _P, _P, _P, _P, _P, C.c_uint32,
-      _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+      _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     ("brush_normalize_quats", C.c_int, [_P, _P, C.c_uint32, _P]),
     ("brush_refine_stats", C.c_int,
      [C.POINTER(BrushAux), _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),

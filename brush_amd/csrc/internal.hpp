@@ -51,6 +51,9 @@ struct AdamFuse {
     float lr[5];                                           // means, log_scales, rotation, raw_opac, sh (dc)
     float sh_lerp, beta1, beta2, eps, bc1, bc2;
     uint32_t quat_vjp, vec_ok;
+    float *norm_rot_out;                                   // optional [N,4]: updated rotation / |rotation| (next forward's input)
+    float *grad_2d_accum, *xy_grad_counts;                 // optional [N]: refinement statistics (train.rs:284-316)
+    float half_w, half_h;
 };
 hipError_t launch_project_backward(const ViewParams &vp, const float *means, const float *log_scales,
                                    const float *quats, const float *raw_opac,

@@ -302,6 +302,15 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
                 r.w = adam_elem(af, e + 3, gq.w, r.w, af.lr[2]);
             }
             reinterpret_cast<float4 *>(af.rotation)[g_own] = r;
+            if (af.norm_rot_out) {  // what the next forward will be fed (gaussian_splats.rs:174-175)
+                const float s = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+                reinterpret_cast<float4 *>(af.norm_rot_out)[g_own] = make_float4(r.x / s, r.y / s, r.z / s, r.w / s);
+            }
+            if (af.grad_2d_accum) {  // train.rs:284-316
+                const float vx = o_xy[0] * af.half_w, vy = o_xy[1] * af.half_h;
+                af.grad_2d_accum[g_own] += sqrtf(vx * vx + vy * vy);
+                if (c_own != kInvalid) af.xy_grad_counts[g_own] += 1.0f;
+            }
             af.raw_opac[g_own] = adam_elem(af, 10 * nn + g_own, o_opac, af.raw_opac[g_own], af.lr[3]);
         }
     }

@@ -294,8 +294,9 @@ extern "C" int brush_render_backward_adam(const BrushUniforms *h_uniforms, const
                                           const BrushAdamConfig *cfg, float *means, float *log_scales,
                                           const float *quats_fed, float *rotation, float *raw_opacity, float *sh,
                                           uint32_t n, const float *out_img, const float *v_out, float *v_xy,
-                                          float *moment1, float *moment2, void *workspace, size_t workspace_bytes,
-                                          brush_stream_t stream) {
+                                          float *moment1, float *moment2, float *next_quats_fed,
+                                          float *grad_2d_accum, float *xy_grad_counts, void *workspace,
+                                          size_t workspace_bytes, brush_stream_t stream) {
     if (!cfg || cfg->time == 0 || !h_uniforms || h_uniforms->sh_degree > 4) return BRUSH_ERR_INVALID_ARG;
     if (n > 0 && (!rotation || !sh || !moment1 || !moment2)) return BRUSH_ERR_INVALID_ARG;
     auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -309,6 +310,11 @@ extern "C" int brush_render_backward_adam(const BrushUniforms *h_uniforms, const
     af.bc1 = 1.0f - powf(cfg->beta1, (float)cfg->time);
     af.bc2 = 1.0f - powf(cfg->beta2, (float)cfg->time);
     af.quat_vjp = cfg->rotation_grad_wrt_normalized;
+    if (next_quats_fed && !aligned(next_quats_fed)) return BRUSH_ERR_INVALID_ARG;
+    if ((grad_2d_accum == nullptr) != (xy_grad_counts == nullptr)) return BRUSH_ERR_INVALID_ARG;
+    af.norm_rot_out = next_quats_fed;
+    af.grad_2d_accum = grad_2d_accum, af.xy_grad_counts = xy_grad_counts;
+    af.half_w = (float)h_uniforms->img_size[0] / 2.0f, af.half_h = (float)h_uniforms->img_size[1] / 2.0f;
     af.vec_ok = (n % 4 == 0) && aligned(means) && aligned(log_scales) && aligned(sh) && aligned(moment1) &&
                 aligned(moment2);
     return render_backward_impl(h_uniforms, h_aux, means, log_scales, quats_fed, raw_opacity, n, out_img, v_out,

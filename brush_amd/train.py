@@ -112,6 +112,7 @@ class SplatTrainer:
         self.moment2 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
         self.opt_time = 0  # Adam's per-parameter step count (reset with the optimizer at refinement)
         self.fused_backward = True  # single view: brush_render_backward_adam instead of backward + brush_adam_step
+        self._norm_rot, self._norm_rot_key = None, None  # rotation/|rotation| left by the previous fused backward
         self.last_refine: Optional[RefineStats] = None
         self.rng = torch.Generator(device=dev)
         self.rng.manual_seed(self.config.seed)
@@ -205,9 +206,16 @@ class SplatTrainer:
             assert t.is_contiguous() and t.dtype == torch.float32
         l = _lib.lib()
         stream = torch.cuda.current_stream(means.device).cuda_stream
-        norm_rot = torch.empty_like(quats)  # Splats::render feeds rotation / |rotation| (gaussian_splats.rs:174-175)
-        with torch.cuda.device(means.device):
-            _lib.check(l.brush_normalize_quats(quats.data_ptr(), norm_rot.data_ptr(), n, stream), "brush_normalize_quats")
+        # Splats::render feeds rotation / |rotation| (gaussian_splats.rs:174-175).  The fused backward of the
+        # previous step already wrote it for the updated rotation; recompute when anyone else touched it.
+        key = (quats.data_ptr(), n, splats.rotation._version)
+        if self._norm_rot is not None and self._norm_rot_key == key:
+            norm_rot = self._norm_rot
+        else:
+            norm_rot = torch.empty_like(quats)
+            with torch.cuda.device(means.device):
+                _lib.check(l.brush_normalize_quats(quats.data_ptr(), norm_rot.data_ptr(), n, stream), "brush_normalize_quats")
+        self._norm_rot = None
         pred, aux, u = R._forward_impl(camera, (w, h), means, log_scales, norm_rot, sh, raw_opac, False, None)
         loss, v_pred = l1_ssim_loss(pred, gt_image, c.ssim_weight, c.ssim_window_size, 1.0 / batch_views)
         do_refine = self.iter < c.max_refine_step and self.iter >= c.warmup_steps and self.iter % c.refine_every == 1
@@ -226,15 +234,17 @@ class SplatTrainer:
                 ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=means.device)
                 v_xy = torch.empty((max(n, 1), 2), dtype=torch.float32, device=means.device)
                 s_aux = aux._as_struct()
+                next_rot = torch.empty_like(quats)
                 _lib.check(l.brush_render_backward_adam(C.byref(u), C.byref(s_aux), C.byref(cfg), means.data_ptr(),
                                                         log_scales.data_ptr(), norm_rot.data_ptr(), quats.data_ptr(),
                                                         raw_opac.data_ptr(), sh.data_ptr(), n, pred.data_ptr(),
                                                         v_pred.data_ptr(), v_xy.data_ptr(), self.moment1.data_ptr(),
-                                                        self.moment2.data_ptr(), ws.data_ptr(), nbytes.value, stream),
+                                                        self.moment2.data_ptr(), next_rot.data_ptr(),
+                                                        self.grad_2d_accum.data_ptr() if want_stats else None,
+                                                        self.xy_grad_counts.data_ptr() if want_stats else None,
+                                                        ws.data_ptr(), nbytes.value, stream),
                            "brush_render_backward_adam")
-                if want_stats:
-                    _lib.check(l.brush_refine_stats(C.byref(s_aux), v_xy.data_ptr(), n, w, h, self.grad_2d_accum.data_ptr(),
-                                                    self.xy_grad_counts.data_ptr(), stream), "brush_refine_stats")
+                self._norm_rot, self._norm_rot_key = next_rot, (quats.data_ptr(), n, splats.rotation._version)
             else:
                 grads, block = R._backward_impl(u, aux, means, log_scales, norm_rot, raw_opac, ncoef, pred, v_pred)
                 if grad_sync is not None:  # view-sharded data parallelism: sum the per-view gradients

@@ -214,12 +214,16 @@ int brush_adam_step(const BrushAdamConfig *cfg, uint32_t n, uint32_t sh_degree, 
  * dense gradients (52+12C bytes per splat) never travel to HBM and back.  Same arguments as the two
  * calls it replaces: `quats_fed` is the [N,4] array the forward was fed (rotation/|rotation| when
  * cfg->rotation_grad_wrt_normalized), `rotation` the raw parameter; means / log_scales / rotation /
- * raw_opacity / sh are updated in place, v_xy [N,2] is still written (refinement statistics).
- * Single-view training only: data-parallel training needs the gradients (brush_render_backward). */
+ * raw_opacity / sh are updated in place, v_xy [N,2] is still written.  Optional outputs (NULL to
+ * skip): next_quats_fed [N,4] = updated rotation / |rotation| (what the next forward is fed, saves
+ * brush_normalize_quats; must not alias quats_fed); grad_2d_accum / xy_grad_counts [N] updated as
+ * brush_refine_stats does.  Single-view training only: data-parallel training needs the gradients
+ * (brush_render_backward). */
 int brush_render_backward_adam(const BrushUniforms *uniforms, const BrushAux *aux, const BrushAdamConfig *cfg,
                                float *means, float *log_scales, const float *quats_fed, float *rotation,
                                float *raw_opacity, float *sh, uint32_t n, const float *out_img,
                                const float *v_out, float *v_xy, float *moment1, float *moment2,
+                               float *next_quats_fed, float *grad_2d_accum, float *xy_grad_counts,
                                void *workspace, size_t workspace_bytes, brush_stream_t stream);
 /* normalized[i] = rotation[i] / |rotation[i]| (gaussian_splats.rs:174-175); [N,4], 16-byte aligned. */
 int brush_normalize_quats(const float *rotation, float *normalized, uint32_t n, brush_stream_t stream);
