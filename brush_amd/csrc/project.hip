@@ -156,10 +156,10 @@ __device__ __forceinline__ SplatWalk load_walk(const ViewParams &vp, const float
     return s;
 }
 
-// ---- ProjectSplats: cull + depth key ------------------------------------------------------
-// project_forward.wgsl:15-68.  One splat per lane; 40 B read, 8 B written per splat.  Being the
-// first launch of the forward pass it also publishes the uniforms buffer and clears the counters
-// and tile_bins (render.rs:102-116,241-244) so that no separate init launch is needed.
+// ---- ProjectSplats: cull + depth key (+ the survivors' ProjectedSplat record) -------------------
+// project_forward.wgsl:15-68 and project_visible.wgsl:163-258.  Being the first launch of the forward
+// pass it also publishes the uniforms buffer and clears the counters and tile_bins
+// (render.rs:102-116,241-244) so that no separate init launch is needed.
 // SH -> colour with the WGSL expression tree (project_visible.wgsl:51-147,232-241).
 template <int DEG>
 __device__ __forceinline__ void sh_colour(const ViewParams &vp, const float mean[3], const float *__restrict__ sh,

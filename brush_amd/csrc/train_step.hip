@@ -6,12 +6,15 @@
 //   k_ssim_forward / k_ssim_backward : loss = L1*(1-w) - SSIM*w (train.rs:243-268) with the SSIM of
 //       ssim.rs:42-101 (11x11 Gaussian window sigma 1.5, zero padding div_ceil(11,2) = 6, so the SSIM
 //       map is (h+2)x(w+2); variances clamped at 0) and d loss / d pred.  The window is outer(g, g), so
-//       every blur is two 1-D passes through LDS (same linear operator, ssim.rs:17-32 notes it as a TODO).
+//       every blur is two 1-D passes (same linear operator, ssim.rs:17-32 notes it as a TODO): horizontal
+//       through a per-wave LDS row buffer, vertical over a register ring while the wave marches down.
 //   k_adam : Adam with the reference's five learning rates and the SH-rest lerp (train.rs:318-359) over
-//       the contiguous gradient block the backward writes; update rule of burn 0.16 `Adam::step`
-//       (m/(1-b1^t) / (sqrt(v/(1-b2^t)) + eps)), eps = 1e-15 (train.rs:184).
-//   k_refine_stats : train.rs:284-316.
-// Roofline: HBM streaming (loss ≈ 150 B/pixel, Adam 28 B/parameter).
+//       the gradient arrays the backward writes; update rule of burn 0.16 `Adam::step`
+//       (m/(1-b1^t) / (sqrt(v/(1-b2^t)) + eps)), eps = 1e-15 (train.rs:184).  The single-view trainer uses
+//       the fused form instead (project_bwd.hip, brush_render_backward_adam).
+//   k_normalize_quats, k_refine_stats : gaussian_splats.rs:174-175, train.rs:284-316.
+// Roofline: the blur kernels are VALU-issue bound (~200 instructions per pixel-channel-row), Adam is an
+// HBM stream (28 B/parameter).
 #include "internal.hpp"
 
 namespace brush {
