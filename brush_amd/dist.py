@@ -209,25 +209,61 @@ def expand_view_records_torch(recs: torch.Tensor, view_rows: torch.Tensor, campo
     return block
 
 
+def _padded_rows(count: int) -> int:
+    return max(256, -(-int(count) // 256) * 256)
+
+
+# rows used by the previous exchange of the same (group, cloud size), with headroom: lets the next
+# exchange be enqueued before the host has seen the new counts (they are all-gathered, hence the
+# same on every rank, so every rank sizes its collectives identically).
+_ROWS_HINT = {}
+
+
 def allreduce_param_grads_compact(block: torch.Tensor, aux: RenderAux, means: torch.Tensor, n: int, ncoef: int,
                                   group: Optional[dist.ProcessGroup] = None, pack=None, expand=None) -> torch.Tensor:
     """Same result as allreduce_param_grads (sum over views, on every rank) through an all-gather of
-    compact per-view records.  One all-gather of the per-view counts (with a host read) sizes the
-    padded record exchange."""
+    compact per-view records.  One 16-byte all-gather carries the per-view counts that size the padded
+    record exchange.  On the GPU the exchange is enqueued optimistically with the previous step's
+    size (+12.5 %) while the counts travel to the host asynchronously; they are checked before the
+    expansion and, should a view have outgrown the hint, pack + all-gather are simply repeated at the
+    right size — the host never leaves the GPU idle waiting for a number."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return block
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = block.device
+    pack = pack or pack_view_records
     # one small message per rank: [num_visible | viewmat[3].xyz bits] (SURVEY §2b-1 for the camera term)
     meta = torch.cat([aux.num_visible.reshape(-1)[:1].to(torch.int32), aux.uniforms_buffer[12:15].to(torch.int32)])
     metas = torch.empty((world, 4), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(metas.view(-1), meta, group=group)
     counts = metas[:, 0].contiguous()
     cams = metas[:, 1:4].contiguous().view(torch.float32)
-    rows = max(256, -(-int(counts.max().item()) // 256) * 256)  # host read: sizes the padded exchange
-    rec = (pack or pack_view_records)(block, aux, n, ncoef, rows)
-    recs = torch.empty((world, rows, _REC), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(recs.view(-1), rec.view(-1), group=group)
+
+    def exchange(rows):
+        rec = pack(block, aux, n, ncoef, rows)
+        recs = torch.empty((world, rows, _REC), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(recs.view(-1), rec.view(-1), group=group)
+        return recs
+
+    key = (id(group), world, n, ncoef, str(dev))
+    hint = _ROWS_HINT.get(key)
+    recs = None
+    if block.is_cuda and hint is not None:
+        host = torch.empty(world, dtype=torch.int32, pin_memory=True)
+        host.copy_(counts, non_blocking=True)
+        seen = torch.cuda.Event()
+        seen.record()
+        recs, rows = exchange(hint), hint  # enqueued while the counts are still on their way
+        seen.synchronize()
+        max_count = int(host.max())
+        if max_count > rows:  # a view outgrew the hint: redo at the right size (same decision on every rank)
+            recs = None
+    else:
+        max_count = int(counts.max().item())
+    if recs is None:
+        rows = _padded_rows(max_count)
+        recs = exchange(rows)
+    _ROWS_HINT[key] = _padded_rows(max_count + max_count // 8)
     return (expand or expand_view_records)(recs, counts, cams, means, block, n, ncoef, rank)
 
 
