@@ -287,7 +287,7 @@ def main():
             "value": round(value, 3), "unit": "views/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"S1: {n} splats @{w}x{h}, SH degree {deg}, seed 4, mean_mult {args.mean_mult}, "
+            "config": {"workload": f"{'S1' if (n, w, h, deg, args.mean_mult) == (1 << 20, 1920, 1080, 3, 1.0) else 'custom'}: {n} splats @{w}x{h}, SH degree {deg}, seed 4, mean_mult {args.mean_mult}, "
                                    f"fwd+bwd per view", "views_per_step": n_gpus,
                        "parallelism": f"view-sharded dp{n_gpus}" if n_gpus > 1 else "single GPU",
                        "gradient_exchange": None if n_gpus == 1 else (
