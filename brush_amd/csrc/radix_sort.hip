@@ -13,8 +13,8 @@
 //                 block scan of totals[]; scatter.
 // The element count stays on the device (*d_n): grids are sized for max_n and surplus blocks exit
 // on their first instruction.  The tile size is also chosen ON THE DEVICE from *d_n (1, 2, 4, 8 or
-// 16 keys per lane, the smallest that keeps the tile count <= 1024): a 100 k-key sort then spreads
-// over ~400 workgroups instead of 25, and an 8 M-key sort still uses 4096-key tiles.  All three
+// 16 keys per lane, the smallest that keeps the tile count <= 256 — measured optimum of 64..2048): a 100 k-key sort then spreads
+// over ~200 workgroups instead of 25, and an 8 M-key sort still uses 4096-key tiles.  All three
 // kernels derive the same value, so the partition is consistent.
 // Stability: tiles, wave chunks, rounds and lanes are all ranked in index order.
 // Traffic per pass: 4 B/key (upsweep) + 16 B/pair (downsweep).  Roofline: HBM at large n, launch
@@ -27,10 +27,10 @@ namespace {
 constexpr uint32_t kSortThreads = 256;
 constexpr uint32_t kSortWaves = kSortThreads / kWave;
 constexpr uint32_t kSortMaxItems = 16;
-constexpr uint32_t kSortTargetTiles = 1024;
+constexpr uint32_t kSortTargetTiles = 256;
 constexpr uint32_t kRadix = 256;
 
-// Keys per lane for a sort of n keys: smallest power of two K in [1,16] with n/(256 K) <= 1024.
+// Keys per lane for a sort of n keys: smallest power of two K in [1,16] with n/(256 K) <= 256.
 __host__ __device__ __forceinline__ uint32_t sort_items(uint32_t n) {
     uint32_t k = 1;
     while (k < kSortMaxItems && (uint64_t)kSortThreads * k * kSortTargetTiles < n) k <<= 1;
