@@ -178,7 +178,7 @@ def _assert_forward_parity(gpu, orc, w, h):
     return V, I
 
 
-def _assert_grad_parity(gpu, orc, rtol=2e-4):
+def _assert_grad_parity(gpu, orc, rtol=2e-4, direct_atol_frac=2e-5):
     """GPU (f32 lane/wave sums + f32 atomics, unspecified order) vs the oracle (f64 tile sums).
 
     |a-b| <= rtol*|b| + atol_frac*max|b|, against two oracle runs:
@@ -189,8 +189,8 @@ def _assert_grad_parity(gpu, orc, rtol=2e-4):
       * the oracle's own forward state (end to end): 1e-3 of the scale (see _run_pair).
     The reference's own test holds v_quats to 1e-1 and the rest to rtol 1e-4 (render.rs:815-830)."""
     for name, key, atol_frac in (("v_means", "v_means", 2e-4), ("v_scales", "v_scales", 2e-4),
-                                 ("v_quats", "v_quats", 2e-4), ("v_sh", "v_sh", 2e-5), ("v_opac", "v_opac", 2e-5),
-                                 ("v_xy", "v_xy", 2e-5)):
+                                 ("v_quats", "v_quats", 2e-4), ("v_sh", "v_sh", direct_atol_frac),
+                                 ("v_opac", "v_opac", direct_atol_frac), ("v_xy", "v_xy", direct_atol_frac)):
         a = gpu[name].detach().cpu().numpy().astype(np.float64)
         e2e = orc["grads"][key].astype(np.float64).reshape(a.shape)
         s2 = np.abs(e2e).max() + 1e-30
@@ -352,6 +352,18 @@ def test_raster_u32(dev):
     for k in range(4):
         assert np.abs(ch(a, k) - ch(o_out, k)).max() <= 1
     assert (a == o_out).mean() > 0.99
+
+
+def test_headline_size_matches_oracle(dev):
+    """The headline configuration itself (1 048 576 splats @1920x1080, SH degree 3, the bench's seed):
+    integer state bit-exact, pixels and gradients within the stated tolerances, against the oracle."""
+    cloud = H.synthetic_cloud(1 << 20, 3, seed=4, mean_mult=1.0)
+    gpu, orc = _run_pair(dev, cloud, 1920, 1080, 3)
+    V, I = _assert_forward_parity(gpu, orc, 1920, 1080)
+    assert V > 100000 and I > 400000
+    # splats that cover the whole 120x68 tile grid sum 8160 float-atomic partials in unspecified order:
+    # the direct sums get the same 2e-4 of the tensor's scale as the projected ones
+    _assert_grad_parity(gpu, orc, direct_atol_frac=2e-4)
 
 
 def test_headline_size_properties(dev):
