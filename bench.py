@@ -55,7 +55,7 @@ def parse():
 
 def synthetic_cloud(n, sh_degree, seed=4, mean_mult=1.0):
     """Host-generated so that CPU and GPU see identical bits."""
-    from tests.helpers import synthetic_cloud as gen
+    from tests.synthetic import synthetic_cloud as gen
 
     return gen(n, sh_degree, seed=seed, mean_mult=mean_mult)
 

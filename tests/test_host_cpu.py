@@ -87,3 +87,23 @@ def test_no_cpu_fallback():
         brush_amd.render_splats(cam, (32, 32), z((4, 3)), None, z((4, 3)), z((4, 4)), z((4, 1, 3)), z((4,)))
     with pytest.raises(AssertionError):
         brush_amd.prefix_sum(torch.zeros(4, dtype=torch.int32))
+
+
+def test_product_and_bench_do_not_import_the_oracle():
+    """The oracle is test infrastructure: importing the package, or bench.py up to its timed path
+    (synthetic inputs included), must not load it; only bench.py's cpu_baseline leg and the tests do."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, importlib.util; sys.argv=['bench.py']; import brush_amd; "
+            "spec=importlib.util.spec_from_file_location('b','bench.py'); m=importlib.util.module_from_spec(spec); "
+            "spec.loader.exec_module(m); m.synthetic_cloud(8, 1); "
+            "print(sorted(k for k in sys.modules if k.split('.')[0] == 'oracle'))")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "[]"
+    for dirpath, _, files in os.walk(os.path.join(root, "brush_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read(), f

@@ -1,16 +1,16 @@
 import torch, time, sys
 sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
-import helpers as H
+import math
+from tests.synthetic import synthetic_cloud
 from brush_amd import dist as BD, render as R
 import brush_amd
 dev = torch.device("cuda:0")
 n, w, h, deg = 1<<20, 1920, 1080, 3
 C = 16
-cloud = H.synthetic_cloud(n, deg, seed=4)
+cloud = synthetic_cloud(n, deg, seed=4)
 p = {k: torch.from_numpy(v).to(dev) for k, v in cloud.items()}
-c = H.reference_test_camera(w, h)
-cam = brush_amd.Camera(c["position"], c["rotation_xyzw"], c["fov_x"], c["fov_y"], c["center_uv"])
+focal = brush_amd.fov_to_focal(math.pi * 0.5, w)  # render_bench.rs:163-174: (0,0,-8), fov 90 deg on x
+cam = brush_amd.Camera([0.0, 0.0, -8.0], [0.0, 0.0, 0.0, 1.0], brush_amd.focal_to_fov(focal, w), brush_amd.focal_to_fov(focal, h), (0.5, 0.5))
 out, aux, u = R._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"], False, brush_amd._lib.lib().brush_default_max_intersects(n, w, h))
 v_out = torch.randn((h, w, 4), device=dev) / (h*w)
 g, block = R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], C, out, v_out)

@@ -1,15 +1,16 @@
 """Runs a few full training iterations on the S1 workload (for rocprofv3 --kernel-trace --stats)."""
 import sys, time
 import torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import helpers as H
+sys.path.insert(0, ".")
+import math
+from tests.synthetic import synthetic_cloud
 import brush_amd
 dev = torch.device("cuda:0")
 n, w, h, deg = 1 << 20, 1920, 1080, 3
-cloud = H.synthetic_cloud(n, deg, seed=4)
+cloud = synthetic_cloud(n, deg, seed=4)
 p = {k: torch.from_numpy(v).to(dev) for k, v in cloud.items()}
-c = H.reference_test_camera(w, h)
-cam = brush_amd.Camera(c["position"], c["rotation_xyzw"], c["fov_x"], c["fov_y"], c["center_uv"])
+focal = brush_amd.fov_to_focal(math.pi * 0.5, w)  # render_bench.rs:163-174: (0,0,-8), fov 90 deg on x
+cam = brush_amd.Camera([0.0, 0.0, -8.0], [0.0, 0.0, 0.0, 1.0], brush_amd.focal_to_fov(focal, w), brush_amd.focal_to_fov(focal, h), (0.5, 0.5))
 splats = brush_amd.Splats(p["means"], p["sh"], p["quats"], p["raw_opac"], p["log_scales"])
 trainer = brush_amd.SplatTrainer(splats, brush_amd.TrainConfig(warmup_steps=0, max_refine_step=0))
 gt = torch.rand((h, w, 3), dtype=torch.float32, device=dev)
