@@ -69,6 +69,17 @@ __global__ __launch_bounds__(kThreads) void k_zero_compact_grads(const uint32_t 
         v_compact[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+// Streaming 16-byte accesses: data that is touched once per step and is far larger than the caches.
+__device__ __forceinline__ float4 nt_load4(const float *p) {
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float *p, float4 v) {
+    const v4f nv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(p));
+}
+
 // One Adam update of burn 0.16 `Adam::step` (see train_step.hip:k_adam) on element `e` of the moment
 // arrays; returns the stepped parameter value.
 __device__ __forceinline__ float adam_elem(const AdamFuse &a, size_t e, float g, float x, float lr) {
@@ -78,7 +89,7 @@ __device__ __forceinline__ float adam_elem(const AdamFuse &a, size_t e, float g,
     return x - ((m / a.bc1) / (sqrtf(v / a.bc2) + a.eps)) * lr;
 }
 __device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4 g, float4 x, float lr) {
-    const float4 mo = *reinterpret_cast<const float4 *>(a.m1 + e), vo = *reinterpret_cast<const float4 *>(a.m2 + e);
+    const float4 mo = nt_load4(a.m1 + e), vo = nt_load4(a.m2 + e);
     float4 m, v, r;
 #define BRUSH_ADAM_C(c)                                                        \
     m.c = mo.c * a.beta1 + g.c * (1.0f - a.beta1);                             \
@@ -86,8 +97,8 @@ __device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4
     r.c = x.c - ((m.c / a.bc1) / (sqrtf(v.c / a.bc2) + a.eps)) * lr;
     BRUSH_ADAM_C(x) BRUSH_ADAM_C(y) BRUSH_ADAM_C(z) BRUSH_ADAM_C(w)
 #undef BRUSH_ADAM_C
-    *reinterpret_cast<float4 *>(a.m1 + e) = m;
-    *reinterpret_cast<float4 *>(a.m2 + e) = v;
+    nt_store4(a.m1 + e, m);
+    nt_store4(a.m2 + e, v);
     return r;
 }
 
@@ -342,9 +353,9 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
                         e[i] = stage[(f / rowf) * stride + (f % rowf)];
                     }
                     if (!ADAM) {
-                        *reinterpret_cast<float4 *>(dst + j) = v;
+                        nt_store4(dst + j, v);  // write-once stream
                     } else {
-                        const float4 x = *reinterpret_cast<const float4 *>(dst + j);
+                        const float4 x = nt_load4(dst + j);
                         float4 st = adam_elem4(af, seg + j, v, x, lr);
                         if (is_sh) {
                             const uint32_t k0 = j % rowf;  // position in the SH row; rows are rowf floats
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
                             st.z = (k0 + 2) % rowf >= 3 ? x.z * (1.0f - af.sh_lerp) + st.z * af.sh_lerp : st.z;
                             st.w = (k0 + 3) % rowf >= 3 ? x.w * (1.0f - af.sh_lerp) + st.w * af.sh_lerp : st.w;
                         }
-                        *reinterpret_cast<float4 *>(dst + j) = st;
+                        nt_store4(dst + j, st);
                     }
                 } else {
                     for (uint32_t f = j; f < total; f++) one(f);

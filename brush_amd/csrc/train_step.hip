@@ -294,11 +294,12 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a, float *__restrict__ me
     else if (e0 < 11 * n) p = raw_opac, grad = g_opac, rel = e0 - 10 * n, lr = a.lr[3];
     else p = sh, grad = g_sh, rel = e0 - 11 * n, lr = a.lr[4], is_sh = true;
     float g[VEC], mo[VEC], ve[VEC], x[VEC];
+    typedef float v4f __attribute__((ext_vector_type(4)));  // streaming (non-temporal) 16-byte accesses
     if constexpr (VEC == 4) {
-        *reinterpret_cast<float4 *>(g) = *reinterpret_cast<const float4 *>(grad + rel);
-        *reinterpret_cast<float4 *>(mo) = *reinterpret_cast<const float4 *>(m1 + e0);
-        *reinterpret_cast<float4 *>(ve) = *reinterpret_cast<const float4 *>(m2 + e0);
-        *reinterpret_cast<float4 *>(x) = *reinterpret_cast<const float4 *>(p + rel);
+        *reinterpret_cast<v4f *>(g) = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(grad + rel));
+        *reinterpret_cast<v4f *>(mo) = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(m1 + e0));
+        *reinterpret_cast<v4f *>(ve) = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(m2 + e0));
+        *reinterpret_cast<v4f *>(x) = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p + rel));
     } else {
         g[0] = grad[rel], mo[0] = m1[e0], ve[0] = m2[e0], x[0] = p[rel];
     }
@@ -345,9 +346,9 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a, float *__restrict__ me
         k = k + 1 == row ? 0 : k + 1;
     }
     if constexpr (VEC == 4) {
-        *reinterpret_cast<float4 *>(m1 + e0) = *reinterpret_cast<float4 *>(mo);
-        *reinterpret_cast<float4 *>(m2 + e0) = *reinterpret_cast<float4 *>(ve);
-        *reinterpret_cast<float4 *>(p + rel) = *reinterpret_cast<float4 *>(x);
+        __builtin_nontemporal_store(*reinterpret_cast<v4f *>(mo), reinterpret_cast<v4f *>(m1 + e0));
+        __builtin_nontemporal_store(*reinterpret_cast<v4f *>(ve), reinterpret_cast<v4f *>(m2 + e0));
+        __builtin_nontemporal_store(*reinterpret_cast<v4f *>(x), reinterpret_cast<v4f *>(p + rel));
     } else {
         m1[e0] = mo[0], m2[e0] = ve[0], p[rel] = x[0];
     }
