@@ -16,6 +16,7 @@ a switch.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -209,8 +210,9 @@ def expand_view_records_torch(recs: torch.Tensor, view_rows: torch.Tensor, campo
     return block
 
 
-def _padded_rows(count: int) -> int:
-    return max(256, -(-int(count) // 256) * 256)
+def _padded_rows(count: int, chunks: int = 1) -> int:
+    q = 256 * chunks
+    return max(q, -(-int(count) // q) * q)
 
 
 # rows used by the previous exchange of the same (group, cloud size), with headroom: lets the next
@@ -239,32 +241,51 @@ def allreduce_param_grads_compact(block: torch.Tensor, aux: RenderAux, means: to
     counts = metas[:, 0].contiguous()
     cams = metas[:, 1:4].contiguous().view(torch.float32)
 
+    # From 4 views on, the records travel in two halves: the expansion of the first half (float atomics,
+    # L2-bound) overlaps the all-gather of the second (xGMI-bound).
+    chunks = int(os.environ.get("BRUSH_EXCHANGE_CHUNKS", "2" if world >= 4 else "1"))
+
     def exchange(rows):
         rec = pack(block, aux, n, ncoef, rows)
-        recs = torch.empty((world, rows, _REC), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(recs.view(-1), rec.view(-1), group=group)
-        return recs
+        per = rows // chunks
+        outs, works = [], []
+        for k in range(chunks):
+            out = torch.empty((world, per, _REC), dtype=torch.float32, device=dev)
+            part = rec[k * per:(k + 1) * per].reshape(-1)
+            works.append(dist.all_gather_into_tensor(out.view(-1), part, group=group, async_op=chunks > 1))
+            outs.append(out)
+        return outs, works, per
 
     key = (id(group), world, n, ncoef, str(dev))
     hint = _ROWS_HINT.get(key)
-    recs = None
+    got = None
     if block.is_cuda and hint is not None:
         host = torch.empty(world, dtype=torch.int32, pin_memory=True)
         host.copy_(counts, non_blocking=True)
         seen = torch.cuda.Event()
         seen.record()
-        recs, rows = exchange(hint), hint  # enqueued while the counts are still on their way
+        got, rows = exchange(hint), hint  # enqueued while the counts are still on their way
         seen.synchronize()
         max_count = int(host.max())
         if max_count > rows:  # a view outgrew the hint: redo at the right size (same decision on every rank)
-            recs = None
+            if chunks > 1:
+                for wk in got[1]:
+                    wk.wait()
+            got = None
     else:
         max_count = int(counts.max().item())
-    if recs is None:
-        rows = _padded_rows(max_count)
-        recs = exchange(rows)
-    _ROWS_HINT[key] = _padded_rows(max_count + max_count // 8)
-    return (expand or expand_view_records)(recs, counts, cams, means, block, n, ncoef, rank)
+    if got is None:
+        rows = _padded_rows(max_count, chunks)
+        got = exchange(rows)
+    _ROWS_HINT[key] = _padded_rows(max_count + max_count // 8, chunks)
+    outs, works, per = got
+    expand = expand or expand_view_records
+    for k in range(chunks):
+        if chunks > 1:
+            works[k].wait()  # the current stream waits for this half only
+        part_rows = counts if chunks == 1 else (counts - k * per).clamp(0, per)
+        expand(outs[k], part_rows, cams, means, block, n, ncoef, rank)
+    return block
 
 
 def densification_stats(v_xy: torch.Tensor, aux: RenderAux, img_size) -> torch.Tensor:

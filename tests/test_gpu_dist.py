@@ -25,7 +25,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, chunks):
+    os.environ["BRUSH_EXCHANGE_CHUNKS"] = str(chunks)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -64,12 +65,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_compact_exchange_two_ranks_one_gpu():
+@pytest.mark.parametrize("chunks", [1, 2])  # 2 = the overlapped two-half exchange used from 4 views on
+def test_compact_exchange_two_ranks_one_gpu(chunks):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
