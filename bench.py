@@ -55,7 +55,7 @@ def parse():
 
 def synthetic_cloud(n, sh_degree, seed=4, mean_mult=1.0):
     """Host-generated so that CPU and GPU see identical bits."""
-    from tests.synthetic import synthetic_cloud as gen
+    from brush_amd.synthetic import synthetic_cloud as gen
 
     return gen(n, sh_degree, seed=seed, mean_mult=mean_mult)
 
@@ -91,9 +91,29 @@ def stage_bytes(stage, n, V, I, P, T, C):
     }[stage]
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (torch.distributed.run on
+    127.0.0.1) from this process, which has not touched the GPU, and exit with their code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(torch.distributed.run --nproc-per-node {args.gpus}) or drop the launcher")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"

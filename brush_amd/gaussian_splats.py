@@ -43,7 +43,15 @@ class Splats(torch.nn.Module):
 
         d = load_splat_from_ply(path_or_bytes)
         t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device)
-        return cls(t(d["means"]), t(d["sh_coeffs"]), t(d["rotation"]), t(d["raw_opacity"]), t(d["log_scales"]))
+        splats = cls(t(d["means"]), t(d["sh_coeffs"]), t(d["rotation"]), t(d["raw_opacity"]), t(d["log_scales"]))
+        splats.norm_rotations()  # every import ends with norm_rotations() (splat_import.rs:139,150)
+        return splats
+
+    @torch.no_grad()
+    def norm_rotations(self):
+        """gaussian_splats.rs:190-196: rotation <- rotation / |rotation|, in place."""
+        rot = self.rotation
+        rot.copy_(rot / torch.sqrt(torch.sum(rot * rot, dim=1, keepdim=True)))
 
     def to_ply(self) -> bytes:
         """crates/brush-dataset/src/splat_export.rs:67-105"""

@@ -1,5 +1,5 @@
-"""Seeded synthetic splat clouds.  Plain numpy, no oracle import: bench.py's timed path and
-the profiling tools use this module, the oracle stays confined to tests / smoke / the cpu_baseline leg."""
+"""Seeded synthetic splat clouds.  Plain numpy: bench.py's timed path, the profiling tools and the
+tests all generate their inputs here, so neither bench.py nor tools/ import the test package or the CPU checker."""
 import math
 
 import numpy as np

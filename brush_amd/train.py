@@ -112,10 +112,18 @@ class SplatTrainer:
         self.moment2 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
         self.opt_time = 0  # Adam's per-parameter step count (reset with the optimizer at refinement)
         self.fused_backward = True  # single view: brush_render_backward_adam instead of backward + brush_adam_step
-        self._norm_rot, self._norm_rot_key = None, None  # rotation/|rotation| left by the previous fused backward
+        # rotation/|rotation| left by the previous fused backward, valid only for the very Parameter object the
+        # trainer updated (identity + storage + autograd version); see invalidate_cached_rotation().
+        self._norm_rot, self._norm_rot_key, self._norm_rot_owner = None, None, None
         self.last_refine: Optional[RefineStats] = None
         self.rng = torch.Generator(device=dev)
         self.rng.manual_seed(self.config.seed)
+
+    def invalidate_cached_rotation(self):
+        """Call after writing `splats.rotation` behind autograd's back (`.data.copy_(ckpt)`, an external
+        kernel): such writes do not bump the tensor version the cache key watches.  In-place ops on the
+        Parameter itself, replacing the Parameter and refine_splats are detected without it."""
+        self._norm_rot, self._norm_rot_key, self._norm_rot_owner = None, None, None
 
     def _reset(self, n: int, ncoef: int, dev):
         """reset_stats + `self.optim = self.opt_config.init()` (train.rs:201-204,559-563)."""
@@ -209,13 +217,13 @@ class SplatTrainer:
         # Splats::render feeds rotation / |rotation| (gaussian_splats.rs:174-175).  The fused backward of the
         # previous step already wrote it for the updated rotation; recompute when anyone else touched it.
         key = (quats.data_ptr(), n, splats.rotation._version)
-        if self._norm_rot is not None and self._norm_rot_key == key:
+        if self._norm_rot is not None and self._norm_rot_key == key and self._norm_rot_owner is splats.rotation:
             norm_rot = self._norm_rot
         else:
             norm_rot = torch.empty_like(quats)
             with torch.cuda.device(means.device):
                 _lib.check(l.brush_normalize_quats(quats.data_ptr(), norm_rot.data_ptr(), n, stream), "brush_normalize_quats")
-        self._norm_rot = None
+        self.invalidate_cached_rotation()
         pred, aux, u = R._forward_impl(camera, (w, h), means, log_scales, norm_rot, sh, raw_opac, False, None)
         loss, v_pred = l1_ssim_loss(pred, gt_image, c.ssim_weight, c.ssim_window_size, 1.0 / batch_views)
         do_refine = self.iter < c.max_refine_step and self.iter >= c.warmup_steps and self.iter % c.refine_every == 1
@@ -245,6 +253,7 @@ class SplatTrainer:
                                                         ws.data_ptr(), nbytes.value, stream),
                            "brush_render_backward_adam")
                 self._norm_rot, self._norm_rot_key = next_rot, (quats.data_ptr(), n, splats.rotation._version)
+                self._norm_rot_owner = splats.rotation
             else:
                 grads, block = R._backward_impl(u, aux, means, log_scales, norm_rot, raw_opac, ncoef, pred, v_pred)
                 if grad_sync is not None:  # view-sharded data parallelism: sum the per-view gradients

@@ -50,5 +50,5 @@ def unnormalised_quat_grad(quats, v_quats):
     return (v - q * np.sum(q * v, axis=1, keepdims=True) / nrm ** 2) / nrm
 
 
-from tests.synthetic import synthetic_cloud  # noqa: E402,F401  (re-exported for the tests)
+from brush_amd.synthetic import synthetic_cloud  # noqa: E402,F401  (re-exported for the tests)
 

@@ -35,6 +35,41 @@ def test_library_exports_every_declared_symbol(lib):
     assert b"gfx950" in lib.brush_version()
 
 
+def test_integration_doc_matches_header():
+    """INTEGRATION.md's Rust FFI block is generated from include/brush_hip.h: regenerate and compare
+    (symbol set, arity and types), and hold the ctypes binding to the same arity per symbol."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    hdr = open(os.path.join(ROOT, "include", "brush_hip.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index(gen.BEGIN) + len(gen.BEGIN):doc.index(gen.END)].strip()
+    assert block == gen.generate(hdr).strip(), "run `python tools/gen_rust_ffi.py --write`"
+    # no second, hand-written extern block that could drift
+    assert doc.count('extern "C" {') == 1
+    structs, funcs = gen.parse_header(hdr)
+    from brush_amd import _lib
+
+    bound = {name: (restype, argtypes) for name, restype, argtypes in _lib._SYMBOLS}
+    assert sorted(bound) == sorted(f[0] for f in funcs)
+    for name, ret, params in funcs:
+        restype, argtypes = bound[name]
+        assert len(argtypes) == len(params), name
+        assert (restype is None) == (ret == "void"), name
+        for (pname, rtype), ct in zip(params, argtypes):
+            is_ptr = rtype.startswith("*")
+            ct_ptr = ct is C.c_void_p or ct is C.c_char_p or hasattr(ct, "contents")
+            assert is_ptr == bool(ct_ptr), f"{name}.{pname}: {rtype} vs {ct}"
+            if not is_ptr:
+                want = {"u32": C.c_uint32, "i32": C.c_int, "f32": C.c_float, "usize": C.c_size_t}[rtype]
+                assert ct is want, f"{name}.{pname}: {rtype} vs {ct}"
+    for sname, fields in structs:
+        cs = getattr(_lib, sname)
+        assert [f[0] for f in cs._fields_] == [f[0] for f in fields], sname
+
+
 def test_argument_validation_without_gpu(lib):
     from brush_amd import _lib
 
@@ -106,4 +141,9 @@ def test_product_and_bench_do_not_import_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(root, "brush_amd")):
         for f in files:
             if f.endswith(".py"):
-                assert "oracle" not in open(os.path.join(dirpath, f)).read(), f
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, f
+                assert not re.search(r"^\s*(from|import)\s+tests\b", src, flags=re.M), f
+    # the bench and the tools do not depend on the test package either
+    for f in ["bench.py"] + [os.path.join("tools", t) for t in os.listdir(os.path.join(root, "tools")) if t.endswith(".py")]:
+        assert not re.search(r"^\s*(from|import)\s+tests\b", open(os.path.join(root, f)).read(), flags=re.M), f

@@ -58,3 +58,24 @@ def test_missing_property_is_an_error():
         P.load_splat_from_ply(hdr + np.zeros(2, "<f4").tobytes())
     with pytest.raises(ValueError):
         P.load_splat_from_ply(b"not a ply")
+
+
+def test_from_ply_normalises_rotations():
+    """Every import ends with Splats::norm_rotations (splat_import.rs:140,150; gaussian_splats.rs:202):
+    non-unit rot_* come back as unit quaternions with the same direction, and re-export keeps them unit."""
+    import torch
+
+    import brush_amd
+
+    d = _cloud(n=7, c=4)
+    d["rotation"] *= np.float32(3.7)
+    blob = P.splat_to_ply(d["means"], d["log_scales"], d["rotation"], d["raw_opacity"], d["sh_coeffs"])
+    raw = P.load_splat_from_ply(blob)
+    assert np.allclose(raw["rotation"], d["rotation"])  # the low-level reader returns the file's values
+    splats = brush_amd.Splats.from_ply(blob, torch.device("cpu"))
+    rot = splats.rotation.detach().numpy()
+    assert np.allclose(np.linalg.norm(rot, axis=1), 1.0, atol=1e-6)
+    want = d["rotation"] / np.linalg.norm(d["rotation"], axis=1, keepdims=True)
+    assert np.allclose(rot, want, atol=1e-6)
+    again = P.load_splat_from_ply(splats.to_ply())
+    assert np.allclose(np.linalg.norm(again["rotation"], axis=1), 1.0, atol=1e-6)

@@ -1,7 +1,7 @@
 import torch, time, sys
 sys.path.insert(0, ".")
 import math
-from tests.synthetic import synthetic_cloud
+from brush_amd.synthetic import synthetic_cloud
 from brush_amd import dist as BD, render as R
 import brush_amd
 dev = torch.device("cuda:0")

@@ -3,7 +3,7 @@ import sys, time
 import torch
 sys.path.insert(0, ".")
 import math
-from tests.synthetic import synthetic_cloud
+from brush_amd.synthetic import synthetic_cloud
 import brush_amd
 dev = torch.device("cuda:0")
 n, w, h, deg = 1 << 20, 1920, 1080, 3
