@@ -27,6 +27,8 @@
 //
 // Roofline: both kernels are fp32-VALU / v_exp_f32 bound, not HBM bound (256 pixel evaluations
 // per 40-byte intersection record); DESIGN.md states both ceilings.
+#include <stdlib.h>
+
 #include "internal.hpp"
 
 namespace brush {
@@ -196,6 +198,169 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32
                     final_index[pix] = fin[j];
                 }
             }
+        }
+    }
+}
+
+// ---- footprint-aware kernels -----------------------------------------------------------------
+//
+// Measured on the headline scene (profiles/r02a_footprint_s1.json): only 26 % of the 256 pixel
+// evaluations of a (tile, splat) record pass `sigma >= 0 && alpha >= 1/255`; at 8x8 granularity a
+// record touches 2.1 of the tile's 4 quadrants on average.  An evaluation that fails the test
+// changes nothing (rasterize.wgsl:80-87, rasterize_backwards.wgsl:229-242), so whole quadrants a
+// splat provably cannot reach are skipped with wave-uniform (scalar) control flow:
+//   * quad_may_pass(): EXACT minimum of the splat's quadratic form over the box of the quadrant's
+//     pixel centres (for a positive-definite conic the constrained minimiser lies on the line through
+//     the box face nearest to the mean in x or in y, see the derivation at the function), turned
+//     into an upper bound of alpha with a slack far above the rounding error of the per-pixel
+//     arithmetic.  A quadrant is skipped only when that bound is below 0.99/255; anything not
+//     provably positive definite / finite is never skipped.
+//   * one lane evaluates the bound for one staged record, a ballot gives the 64-bit hit mask of the
+//     batch, and the compositing loop walks its set bits on the scalar unit.
+// Lane mask of a predicate straight from the compare (HIP's __ballot() converts the bool to an int and
+// compares it again: two VALU instructions per call).
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+constexpr float kHalfNegLog2e = -0.72134752044448170f;  // 2 sigma -> exp2 argument (backward)
+
+// Largest alpha the splat can reach at any point of the box [bx, bx+7] x [by, by+7] (pixel centres
+// of one 8x8 quadrant) >= 1/255 ?  d = mean - pixel ranges over [dxl,dxh] x [dyl,dyh]; q(d) =
+// 0.5 (a dx^2 + c dy^2) + b dx dy is convex with its minimum 0 at d = 0.  If the box does not contain 0
+// the minimiser d* sits on the boundary, and (KKT + positive definiteness) at least one coordinate
+// is at the bound NEAREST to 0 of an axis whose range excludes 0: a minimiser on a far face with
+// the other coordinate free would need dx (a - b^2/c) <= 0, and both coordinates on far faces would
+// need q(d*) <= 0.  So min q = min( min_dy q(ex, dy), min_dx q(dx, ey) ) with ex, ey the clamps of 0
+// into the ranges; each 1-D problem is a clamped parabola vertex.  (If a range contains 0 its line
+// runs through the box: a feasible point, so it can only raise that candidate, never the minimum.)
+__device__ __forceinline__ bool quad_may_pass(float mx, float my, float ca, float cb, float cc, float opac,
+                                              float bx, float by) {
+    const float dxl = mx - (bx + 7.0f), dxh = mx - bx;
+    const float dyl = my - (by + 7.0f), dyh = my - by;
+    const float ex = fminf(fmaxf(0.0f, dxl), dxh), ey = fminf(fmaxf(0.0f, dyl), dyh);
+    // parabola vertices with v_rcp_f32 (1 ulp): q is stationary there, so the error is second order
+    const float y1 = fminf(fmaxf(-cb * ex * __builtin_amdgcn_rcpf(cc), dyl), dyh);
+    const float x2 = fminf(fmaxf(-cb * ey * __builtin_amdgcn_rcpf(ca), dxl), dxh);
+    const float s1 = 0.5f * (ca * ex * ex + cc * y1 * y1), c1 = cb * ex * y1;
+    const float s2 = 0.5f * (ca * x2 * x2 + cc * ey * ey), c2 = cb * x2 * ey;
+    const float qmin = fminf(s1 + c1, s2 + c2);
+    // slack: 0.02 absolute plus 4e-6 of the magnitude of the terms (f32 rounding of the per-pixel
+    // evaluation is ~1e-7 of the same terms)
+    const float slack = 0.02f + 4e-6f * fmaxf(s1 + fabsf(c1), s2 + fabsf(c2));
+    const float amax = opac * __builtin_amdgcn_exp2f((qmin - slack) * kNegLog2e);
+    const bool pd = ca > 0.0f && cc > 0.0f && ca * cc > cb * cb;
+    return !pd || !(amax < 0.99f / 255.0f);  // NaN anywhere -> keep
+}
+
+// v_min_f32 without the canonicalising v_max the IEEE-mode lowering of fminf() puts in front of it.
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// One staged record of the footprint-aware kernels: 48 bytes, read back as wave-uniform broadcasts.
+struct QuadRec {
+    float4 a;  // mean.x, mean.y, conic.x, conic.y
+    float4 b;  // conic.z, r, g, b
+    float4 c;  // opacity, -, -, -
+};
+
+// Forward: ONE wave64 per 8x8 quadrant, one pixel per lane; the four waves of a workgroup are the four
+// quadrants of one tile (they gather the same records, so three of the four gathers hit L1/L2).
+// A pixel that has saturated gets a NaN pixel centre: every later `power <= 0` test fails for it, so the
+// per-record path carries no separate "live" predicate.
+template <bool RASTER_U32>
+__global__ __launch_bounds__(kRasterThreads) void k_rasterize_quad(
+    uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles, const uint32_t *__restrict__ gid_from_isect,
+    const uint32_t *__restrict__ tile_bins, const float *__restrict__ projected, void *__restrict__ out_img,
+    uint32_t *__restrict__ final_index, uint32_t u32_pitch) {
+    __shared__ QuadRec lds_all[kTilesPerBlock][kBatch];
+    const uint32_t q = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    QuadRec *lds = lds_all[q];
+    const uint32_t tile_id = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-contiguous bands
+    if (tile_id >= num_tiles) return;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t qx0 = (tile_id % tbx) * kTileWidth + (q & 1u) * 8u, qy0 = (tile_id / tbx) * kTileWidth + (q >> 1) * 8u;
+    if (qx0 >= w || qy0 >= h) return;  // quadrant entirely outside a ragged frame
+    const uint32_t px = qx0 + (lane & 7u), py = qy0 + (lane >> 3);
+    const float bx = (float)qx0 + 0.5f, by = (float)qy0 + 0.5f;
+    const bool inside = px < w && py < h;
+    const float pcy = (float)py + 0.5f;  // rasterize.wgsl:32
+    float pcx = inside ? (float)px + 0.5f : __builtin_nanf("");
+
+    const uint64_t inside_mask = ballot64(inside);
+    uint64_t live = inside_mask;
+    uint32_t walked = 0;
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb_ = 0.0f;
+    uint32_t fin = 0;
+    const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
+    for (uint32_t batch_start = r0; batch_start < r1 && live != 0ull; batch_start += kBatch) {
+        const uint32_t remaining = min(kBatch, r1 - batch_start);
+        bool hit = false;
+        float rec[9];
+        if (lane < remaining) {
+            const float *p = projected + (size_t)gid_from_isect[batch_start + lane] * BRUSH_PROJECTED_FLOATS;
+#pragma unroll
+            for (int k = 0; k < 9; k++) rec[k] = p[k];
+            hit = quad_may_pass(rec[0], rec[1], rec[2], rec[3], rec[4], rec[8], bx, by);
+        }
+        uint64_t mask = ballot64(hit);
+        if (mask == 0ull) continue;
+        wave_sync();  // the previous batch's broadcasts are done (LDS is in order per wave)
+        if (hit) {
+            lds[lane].a = make_float4(rec[0], rec[1], rec[2], rec[3]);
+            lds[lane].b = make_float4(rec[4], rec[5], rec[6], rec[7]);
+            lds[lane].c = make_float4(rec[8], 0.f, 0.f, 0.f);
+        }
+        wave_sync();
+        while (mask != 0ull) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const float4 a = lds[t].a;
+            const float4 b = lds[t].b;
+            const float opac = lds[t].c.x;
+            // rasterize.wgsl:80-99
+            const float dx = a.x - pcx, dy = a.y - pcy;
+            // The reference's association, 0.5 (a dx^2 + c dy^2) + b dx dy: folding -log2(e)/2 into the conic saves
+            // three instructions but moves alpha by ~1e-5 relative on correlated conics, enough to flip
+            // `alpha >= 1/255` outside the oracle's guard band on a 20 M-splat frame (measured: 3.7e-4 pixel error).
+            const float sigma = fmaf(0.5f, fmaf(a.z * dx, dx, (b.x * dy) * dy), (a.w * dy) * dx);
+            const float power = sigma * kNegLog2e;
+            const float alpha_u = opac * __builtin_amdgcn_exp2f(power);
+            if (power <= 0.0f && alpha_u >= 1.0f / 255.0f) {  // never true for a saturated pixel (NaN)
+                const float alpha = vmin(0.999f, alpha_u);
+                const float next_T = T * (1.0f - alpha);
+                if (next_T <= 1e-4f) {  // :88-91: stop WITHOUT adding this entry
+                    pcx = __builtin_nanf("");
+                } else {
+                    const float fac = alpha * T;
+                    cr = fmaf(b.y, fac, cr);
+                    cg = fmaf(b.z, fac, cg);
+                    cb_ = fmaf(b.w, fac, cb_);
+                    T = next_T;
+                    fin = batch_start + t;
+                }
+            }
+            // all pixels saturated?  one compare every 4th record (the lane mask comes straight out of it)
+            if ((++walked & 3u) == 0u) {
+                live = ~__builtin_amdgcn_fcmp(pcx, pcx, 8 /* FCMP_UNO */) & inside_mask;
+                if (live == 0ull) break;
+            }
+        }
+    }
+    if (inside) {
+        const float al = 1.0f - T;
+        if (RASTER_U32) {
+            // rasterize.wgsl:106-109; rows `u32_pitch` pixels apart (burn_texture.rs:17-26)
+            const uint32_t r8 = (uint32_t)fminf(fmaxf(cr * 255.0f, 0.0f), 255.0f);
+            const uint32_t g8 = (uint32_t)fminf(fmaxf(cg * 255.0f, 0.0f), 255.0f);
+            const uint32_t b8 = (uint32_t)fminf(fmaxf(cb_ * 255.0f, 0.0f), 255.0f);
+            const uint32_t a8 = (uint32_t)fminf(fmaxf(al * 255.0f, 0.0f), 255.0f);
+            static_cast<uint32_t *>(out_img)[(size_t)px + (size_t)py * u32_pitch] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+        } else {
+            const size_t pix = (size_t)px + (size_t)py * w;
+            static_cast<float4 *>(out_img)[pix] = make_float4(cr, cg, cb_, al);
+            final_index[pix] = fin;
         }
     }
 }
@@ -417,10 +582,202 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
     }
 }
 
+// Footprint-aware backward.  A wave owns NQ quadrants of one tile (NQ = 4: one wave per tile, NQ = 2:
+// upper / lower half, NQ = 1: one quadrant), one pixel per lane PER QUADRANT, so a lane's gradient
+// contributions of all its quadrants are summed in registers and the 9-component wave reduction runs
+// once per (wave, record) exactly as before; quadrants the record cannot reach (quad_may_pass) are
+// skipped by scalar branches.  Under the per-pixel `if` the updates are plain (exec-masked) moves,
+// no selects.  sigma is evaluated as 0.5 (dx gx + dy gy) with gx = a dx + b dy, gy = b dx + c dy,
+// which are the v_xy factors of rasterize_backwards.wgsl:260-263 as well.
+template <uint32_t NQ>
+__global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
+    uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles, const uint32_t *__restrict__ gid_from_isect,
+    const uint32_t *__restrict__ tile_bins, const float *__restrict__ projected,
+    const uint32_t *__restrict__ final_index, const float *__restrict__ out_img,
+    const float *__restrict__ v_out, float *__restrict__ v_compact) {
+    __shared__ QuadRec lds_all[kTilesPerBlock][kBatch];
+    __shared__ uint32_t lds_gid_all[kTilesPerBlock][kBatch];
+    __shared__ float acc_all[kTilesPerBlock][kBatch][12];  // 9 used; 48-byte rows keep b128 stores aligned
+    constexpr uint32_t kWavesPerTile = 4u / NQ;
+
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    QuadRec *lds = lds_all[wv];
+    uint32_t *lds_gid = lds_gid_all[wv];
+    float(*acc)[12] = acc_all[wv];
+    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x, wv);
+    const uint32_t tile_id = unit / kWavesPerTile, sub = unit % kWavesPerTile;
+    if (tile_id >= num_tiles) return;
+    const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
+    if (r1 <= r0) return;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t tx0 = (tile_id % tbx) * kTileWidth, ty0 = (tile_id / tbx) * kTileWidth;
+
+    // Per-quadrant pixel state (see k_rasterize_backward for D and K); pixels outside the image get
+    // fin = -1 and never contribute.
+    float pcx[NQ], pcy[NQ], T[NQ], K[NQ], D[NQ], vor[NQ], vog[NQ], vob[NQ];
+    int32_t fin[NQ];
+    int32_t max_fin = -1;
+#pragma unroll
+    for (uint32_t s = 0; s < NQ; s++) {
+        const uint32_t qi = sub * NQ + s;
+        const uint32_t px = tx0 + (qi & 1u) * 8u + (lane & 7u), py = ty0 + (qi >> 1) * 8u + (lane >> 3);
+        pcx[s] = (float)px + 0.5f;
+        pcy[s] = (float)py + 0.5f;
+        float T_final = 1.0f;
+        float4 vo = make_float4(0.f, 0.f, 0.f, 0.f);
+        fin[s] = -1;
+        if (px < w && py < h) {
+            const size_t pix = (size_t)px + (size_t)py * w;
+            T_final = 1.0f - out_img[pix * 4 + 3];  // rasterize_backwards.wgsl:163
+            fin[s] = (int32_t)final_index[pix];
+            vo = reinterpret_cast<const float4 *>(v_out)[pix];
+        }
+        T[s] = T_final, K[s] = T_final * vo.w, D[s] = 0.0f;
+        vor[s] = vo.x, vog[s] = vo.y, vob[s] = vo.z;
+        max_fin = max(max_fin, fin[s]);
+    }
+    // Entries behind the wave's largest final index fail `isect_id <= final_isect` for every pixel
+    // (rasterize_backwards.wgsl:229): start the walk there.
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) max_fin = max(max_fin, __shfl_xor(max_fin, d, 64));
+    const uint32_t walk_end = min(r1, (uint32_t)(max_fin + 1));
+    if (walk_end <= r0) return;
+
+    for (uint32_t batch_end = walk_end; batch_end > r0;) {
+        const uint32_t remaining = min(kBatch, batch_end - r0);
+        bool hitq[NQ];
+#pragma unroll
+        for (uint32_t s = 0; s < NQ; s++) hitq[s] = false;
+        float rec[9];
+        uint32_t cg_id = 0;
+        if (lane < remaining) {
+            cg_id = gid_from_isect[batch_end - 1u - lane];
+            const float *p = projected + (size_t)cg_id * BRUSH_PROJECTED_FLOATS;
+#pragma unroll
+            for (int k = 0; k < 9; k++) rec[k] = p[k];
+#pragma unroll
+            for (uint32_t s = 0; s < NQ; s++) {
+                const uint32_t qi = sub * NQ + s;
+                hitq[s] = quad_may_pass(rec[0], rec[1], rec[2], rec[3], rec[4], rec[8],
+                                        (float)(tx0 + (qi & 1u) * 8u) + 0.5f, (float)(ty0 + (qi >> 1) * 8u) + 0.5f);
+            }
+        }
+        uint64_t qm[NQ], todo = 0ull;
+#pragma unroll
+        for (uint32_t s = 0; s < NQ; s++) {
+            qm[s] = ballot64(hitq[s]);
+            todo |= qm[s];
+        }
+        if (todo == 0ull) {
+            batch_end -= remaining;
+            continue;
+        }
+        wave_sync();  // previous batch fully flushed
+        if ((todo >> lane) & 1ull) {
+            lds_gid[lane] = cg_id;
+            lds[lane].a = make_float4(rec[0], rec[1], rec[2], rec[3]);
+            lds[lane].b = make_float4(rec[4], rec[5], rec[6], rec[7]);
+            lds[lane].c = make_float4(rec[8], 0.f, 0.f, 0.f);
+        }
+        {
+            float4 *row = reinterpret_cast<float4 *>(&acc[lane][0]);
+            row[0] = row[1] = row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        wave_sync();
+        const uint64_t flush_mask = todo;
+        while (todo != 0ull) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int32_t isect_id = (int32_t)(batch_end - 1u - t);
+            const float4 a = lds[t].a;
+            const float4 b = lds[t].b;
+            const float opac = lds[t].c.x;
+            // Zeros the compiler cannot see through: every quadrant then accumulates in place under its
+            // exec mask, instead of each path materialising its own set of nine zero registers.
+            float g[kGradComps];
+#pragma unroll
+            for (uint32_t k = 0; k < kGradComps; k++) asm volatile("v_mov_b32 %0, 0" : "=v"(g[k]));
+            bool contributed = false;
+#pragma unroll
+            for (uint32_t s = 0; s < NQ; s++) {
+                if (((qm[s] >> t) & 1ull) == 0ull) continue;  // scalar: the record cannot reach quadrant s
+                const float dx = a.x - pcx[s], dy = a.y - pcy[s];
+                const float gx = fmaf(a.z, dx, a.w * dy);
+                const float gy = fmaf(a.w, dx, b.x * dy);
+                const float sig2 = fmaf(dx, gx, dy * gy);  // 2 sigma
+                const float vis = __builtin_amdgcn_exp2f(sig2 * kHalfNegLog2e);
+                const float alpha_u = opac * vis;
+                if (isect_id <= fin[s] && sig2 >= 0.0f && alpha_u >= 1.0f / 255.0f) {
+                    // rasterize_backwards.wgsl:239-271
+                    const float alpha = vmin(0.99f, alpha_u);  // 0.99 here, 0.999 in the forward (:239)
+                    const float om = 1.0f - alpha;
+                    float ra = __builtin_amdgcn_rcpf(om);       // 1 - alpha >= 0.01: always finite
+                    ra = fmaf(fmaf(-om, ra, 1.0f), ra, ra);     // one Newton step
+                    const float Tn = T[s] * ra;
+                    const float fac = alpha * Tn;
+                    const float cv = fmaf(b.w, vob[s], fmaf(b.z, vog[s], b.y * vor[s]));
+                    // v_alpha = (c*T - buffer*ra) . v_rgb + T_final*ra*v_a = T (c . v_rgb) + ra (K - D)
+                    const float v_alpha = fmaf(Tn, cv, ra * (K[s] - D[s]));
+                    T[s] = Tn;
+                    D[s] = fmaf(fac, cv, D[s]);
+                    const float vva = vis * v_alpha;  // v_opac term
+                    const float v_sigma = -opac * vva;
+                    const float hs = 0.5f * v_sigma;
+                    g[0] = fmaf(v_sigma, gx, g[0]);
+                    g[1] = fmaf(v_sigma, gy, g[1]);
+                    g[2] = fmaf(hs * dx, dx, g[2]);
+                    g[3] = fmaf(v_sigma * dx, dy, g[3]);
+                    g[4] = fmaf(hs * dy, dy, g[4]);
+                    g[5] = fmaf(fac, vor[s], g[5]);
+                    g[6] = fmaf(fac, vog[s], g[6]);
+                    g[7] = fmaf(fac, vob[s], g[7]);
+                    g[8] += vva;
+                    contributed = true;
+                }
+            }
+            if (ballot64(contributed) != 0ull) {  // wave-uniform: all 64 lanes take part in the reduction
+                const float u0 = fold_swap32(g[0], g[1]), u1 = fold_swap32(g[2], g[3]);
+                const float u2 = fold_swap32(g[4], g[5]), u3 = fold_swap32(g[6], g[7]);
+                const float w0 = row_sum_lane15(fold_swap16(u0, u1));
+                const float w1 = row_sum_lane15(fold_swap16(u2, u3));
+                const float s8 = wave_sum_lane63(g[8]);
+                if ((lane & 15u) == 15u) {
+                    const uint32_t r = lane >> 4;
+                    const uint32_t i0 = ((r & 1u) << 1) | (r >> 1);
+                    acc[t][i0] = w0;
+                    acc[t][4 + i0] = w1;
+                    if (lane == 63) acc[t][8] = s8;
+                }
+            }
+        }
+        wave_sync();
+        // Flush the staged records: one hardware float atomic per (wave, splat, component); consecutive
+        // lanes take consecutive components of one splat.
+        for (uint32_t f = lane; f < remaining * kGradComps; f += kWave) {
+            const uint32_t t = f / kGradComps, k = f - t * kGradComps;
+            if ((flush_mask >> t) & 1ull) {
+                const float v = acc[t][k];
+                if (v != 0.0f) unsafeAtomicAdd(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], v);
+            }
+        }
+        batch_end -= remaining;
+    }
+}
+
 }  // namespace
 
-// Work units (waves) per tile: 1 with 4 pixels per lane when the frame has at least this many
-// tiles, else 2 with 2 pixels per lane.
+// Development switch (A/B timing in one process): BRUSH_RASTER_LEGACY=1 selects the round-1 kernels
+// (every record evaluated on all 256 pixels).
+static bool legacy_raster() {
+    static const bool v = [] {
+        const char *e = getenv("BRUSH_RASTER_LEGACY");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
+// Work units (waves) per tile of the legacy kernels: 1 with 4 pixels per lane when the frame has at
+// least this many tiles, else 2 with 2 pixels per lane.
 constexpr uint32_t kMinTilesForOneWave = 6144;
 
 hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
@@ -429,6 +786,17 @@ hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                             uint32_t *final_index, hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
+    if (!legacy_raster()) {
+        // one workgroup (4 quadrant waves) per tile
+        const dim3 grid(ceil_div(tiles, 8u) * 8u), block(kRasterThreads);
+        if (raster_u32)
+            hipLaunchKernelGGL(k_rasterize_quad<true>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
+                               tile_bins, projected, out_img, final_index, u32_pitch);
+        else
+            hipLaunchKernelGGL(k_rasterize_quad<false>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
+                               tile_bins, projected, out_img, final_index, u32_pitch);
+        return hipGetLastError();
+    }
     const bool wide = tiles >= kMinTilesForOneWave;
     const uint32_t units = tiles * (wide ? 1u : 2u);
     const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
@@ -444,6 +812,17 @@ hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
     return hipGetLastError();
 }
 
+// Quadrants per wave of the backward: fewer waves per tile keep the per-record wave reduction rare,
+// more waves per tile fill the chip when the frame has few tiles.
+static uint32_t backward_quadrants_per_wave(uint32_t tiles) {
+    static const int forced = [] {
+        const char *e = getenv("BRUSH_BWD_NQ");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 1 || forced == 2 || forced == 4) return (uint32_t)forced;
+    return tiles >= 6144u ? 4u : (tiles >= 2048u ? 2u : 1u);
+}
+
 hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                                      const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
                                      const float *projected, const uint32_t *final_index,
@@ -451,6 +830,17 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
                                      hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
+    if (!legacy_raster()) {
+        const uint32_t nq = backward_quadrants_per_wave(tiles);
+        const uint32_t units = tiles * (4u / nq);
+        const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
+#define BRUSH_RASTER_BWD(NQ)                                                                                     \
+    hipLaunchKernelGGL(k_rasterize_backward_quad<NQ>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, \
+                       tile_bins, projected, final_index, out_img, v_out, v_compact)
+        if (nq == 4) BRUSH_RASTER_BWD(4); else if (nq == 2) BRUSH_RASTER_BWD(2); else BRUSH_RASTER_BWD(1);
+#undef BRUSH_RASTER_BWD
+        return hipGetLastError();
+    }
     const bool wide = tiles >= kMinTilesForOneWave;
     const uint32_t units = tiles * (wide ? 1u : 2u);
     const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);

@@ -620,7 +620,7 @@ static void rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
                                     const uint32_t *gid_from_isect, const uint32_t *tile_bins,
                                     const float *projected, const uint32_t *final_index,
                                     const float *out_img, const float *v_out, double *v_xy,
-                                    double *v_conic, double *v_colors) {
+                                    double *v_conic, double *v_colors, float *rows32) {
     uint32_t w = u->img_size[0], h = u->img_size[1];
     uint32_t tbx = u->tile_bounds[0];
     uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
@@ -675,6 +675,21 @@ static void rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
             s_conic[2] += 0.5f * v_sigma * dy * dy;
             s_col[0] += fac * vo[l][0]; s_col[1] += fac * vo[l][1]; s_col[2] += fac * vo[l][2];
             s_col[3] += vis * v_alpha;
+            if (rows32) { /* (double)(float)(a + b) with a, b floats IS the f32 sum a + b */
+                s_xy[0] = (float)s_xy[0]; s_xy[1] = (float)s_xy[1];
+                s_conic[0] = (float)s_conic[0]; s_conic[1] = (float)s_conic[1]; s_conic[2] = (float)s_conic[2];
+                s_col[0] = (float)s_col[0]; s_col[1] = (float)s_col[1]; s_col[2] = (float)s_col[2];
+                s_col[3] = (float)s_col[3];
+            }
+        }
+        if (rows32) {
+            /* f32-sum mode: every addition above is re-done in f32 below; the row is summed per splat in
+             * ascending intersection order by the caller. */
+            float *r = rows32 + (size_t)i * 9;
+            r[0] = (float)s_xy[0]; r[1] = (float)s_xy[1];
+            r[2] = (float)s_conic[0]; r[3] = (float)s_conic[1]; r[4] = (float)s_conic[2];
+            r[5] = (float)s_col[0]; r[6] = (float)s_col[1]; r[7] = (float)s_col[2]; r[8] = (float)s_col[3];
+            continue;
         }
         if (!any) continue;
         for (int k = 0; k < 2; k++) {
@@ -802,12 +817,35 @@ static void project_backward_one(const OracleUniforms *u, const float *mean, con
     v_mean[0] = vm[0]; v_mean[1] = vm[1]; v_mean[2] = vm[2];
 }
 
+/* f32_sums = 0: per-pixel f32 arithmetic, tile and cross-tile sums in f64 (the order-free value the
+ * reference's unordered subgroupAdd / atomics approximate).  f32_sums = 1: every sum in f32 as well,
+ * pixels in tile order, then a splat's tiles in ascending intersection order: one admissible
+ * execution of the reference's own f32 arithmetic, used as the yardstick of the f64 arbiter
+ * (brush_oracle_f64.c). */
+int oracle_render_backward_ex(const OracleUniforms *u_in, const OracleAux *aux, const float *means,
+                              const float *log_scales, const float *quats, const float *raw_opac,
+                              uint32_t n, const float *out_img, const float *v_out, float *v_means,
+                              float *v_xy, float *v_scales, float *v_quats, float *v_sh,
+                              float *v_opac, float *o_v_xy_local, float *o_v_conics,
+                              float *o_v_colors, int f32_sums);
+
 int oracle_render_backward(const OracleUniforms *u_in, const OracleAux *aux, const float *means,
                            const float *log_scales, const float *quats, const float *raw_opac,
                            uint32_t n, const float *out_img, const float *v_out, float *v_means,
                            float *v_xy, float *v_scales, float *v_quats, float *v_sh,
                            float *v_opac, float *o_v_xy_local, float *o_v_conics,
                            float *o_v_colors) {
+    return oracle_render_backward_ex(u_in, aux, means, log_scales, quats, raw_opac, n, out_img, v_out, v_means,
+                                     v_xy, v_scales, v_quats, v_sh, v_opac, o_v_xy_local, o_v_conics,
+                                     o_v_colors, 0);
+}
+
+int oracle_render_backward_ex(const OracleUniforms *u_in, const OracleAux *aux, const float *means,
+                              const float *log_scales, const float *quats, const float *raw_opac,
+                              uint32_t n, const float *out_img, const float *v_out, float *v_means,
+                              float *v_xy, float *v_scales, float *v_quats, float *v_sh,
+                              float *v_opac, float *o_v_xy_local, float *o_v_conics,
+                              float *o_v_colors, int f32_sums) {
     OracleUniforms uu = *u_in;
     uu.total_splats = n;
     const OracleUniforms *u = &uu;
@@ -821,11 +859,28 @@ int oracle_render_backward(const OracleUniforms *u_in, const OracleAux *aux, con
     double *d_col = (double *)calloc(vn * 4, sizeof(double));
 
     /* RasterizeBackwards (render.rs:505-532) */
+    uint32_t I = aux->num_intersections[0];
+    float *rows32 = f32_sums ? (float *)calloc((size_t)(I ? I : 1) * 9, sizeof(float)) : NULL;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int64_t t = 0; t < (int64_t)num_tiles; t++)
         rasterize_backward_tile(u, (uint32_t)t, aux->compact_gid_from_isect, aux->tile_bins,
                                 aux->projected_splats, aux->final_index, out_img, v_out, d_xy,
-                                d_conic, d_col);
+                                d_conic, d_col, rows32);
+    if (rows32) {
+        for (size_t i = 0; i < I; i++) { /* f32 adds, ascending intersection id */
+            size_t c = aux->compact_gid_from_isect[i];
+            const float *r = rows32 + i * 9;
+            d_xy[c * 2] = (float)d_xy[c * 2] + r[0]; d_xy[c * 2 + 1] = (float)d_xy[c * 2 + 1] + r[1];
+            for (int k = 0; k < 3; k++) d_conic[c * 3 + k] = (float)d_conic[c * 3 + k] + r[2 + k];
+            for (int k = 0; k < 4; k++) d_col[c * 4 + k] = (float)d_col[c * 4 + k] + r[5 + k];
+        }
+        for (size_t c = 0; c < (size_t)V; c++) { /* the stored value is the f32 sum */
+            d_xy[c * 2] = (float)d_xy[c * 2]; d_xy[c * 2 + 1] = (float)d_xy[c * 2 + 1];
+            for (int k = 0; k < 3; k++) d_conic[c * 3 + k] = (float)d_conic[c * 3 + k];
+            for (int k = 0; k < 4; k++) d_col[c * 4 + k] = (float)d_col[c * 4 + k];
+        }
+        free(rows32);
+    }
 
     /* dense outputs are zero-initialised (render.rs:539-547,573-575) */
     memset(v_means, 0, sizeof(float) * 3 * n);

@@ -77,6 +77,29 @@ int oracle_render_backward(const OracleUniforms *u, const OracleAux *aux, const 
                            /* optional compact-order intermediates (may be NULL): */
                            float *v_xy_local, float *v_conics, float *v_colors);
 
+/* As above with the summation mode explicit: f32_sums = 1 also sums in f32 (pixels in tile order, a splat's
+ * tiles in ascending intersection order): one admissible execution of the reference's f32 arithmetic. */
+int oracle_render_backward_ex(const OracleUniforms *u, const OracleAux *aux, const float *means,
+                              const float *log_scales, const float *quats, const float *raw_opac,
+                              uint32_t n, const float *out_img, const float *v_out, float *v_means,
+                              float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
+                              float *v_xy_local, float *v_conics, float *v_colors, int f32_sums);
+
+/* brush_oracle_f64.c: the same backward with every value in f64 and the walk's decisions taken as the f32
+ * restatement takes them; all outputs f64.  Arbiter for tolerance questions, never a parity reference itself. */
+int oracle_render_backward_f64(const OracleUniforms *u, const OracleAux *aux, const float *means,
+                               const float *log_scales, const float *quats, const float *raw_opac, uint32_t n,
+                               const float *out_img, const float *v_out, double *v_means, double *v_xy,
+                               double *v_scales, double *v_quats, double *v_sh, double *v_opac,
+                               /* optional (all NULL or none): per-element sum of the magnitudes of the terms */
+                               double *mag_means, double *mag_xy, double *mag_scales, double *mag_quats,
+                               double *mag_sh, double *mag_opac,
+                               /* and what threshold decisions within f32 rounding of flipping can move */
+                               double *flip_means, double *flip_xy, double *flip_scales, double *flip_quats,
+                               double *flip_sh, double *flip_opac,
+                               /* and the magnitude of the terms the projection VJP itself sums */
+                               double *vjp_means, double *vjp_scales, double *vjp_quats);
+
 /* Deterministic elementary functions (oracle/detmath.h), exported for tests. */
 float oracle_det_expf(float x);
 float oracle_det_logf(float x);

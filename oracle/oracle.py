@@ -53,7 +53,8 @@ class _Aux(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with the committed Makefile if it is missing or stale."""
-    srcs = [os.path.join(_HERE, f) for f in ("brush_oracle.c", "brush_oracle.h", "detmath.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("brush_oracle.c", "brush_oracle_f64.c", "brush_oracle.h", "detmath.h",
+                                             "Makefile")]
     stale = not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
@@ -77,6 +78,8 @@ def lib():
         _lib.oracle_num_threads.restype = C.c_int
         _lib.oracle_render_forward.restype = C.c_int
         _lib.oracle_render_backward.restype = C.c_int
+        _lib.oracle_render_backward_ex.restype = C.c_int
+        _lib.oracle_render_backward_f64.restype = C.c_int
     return _lib
 
 
@@ -229,8 +232,9 @@ def render_forward(u: dict, means, log_scales, quats, sh_coeffs, raw_opac, raste
     return out, aux
 
 
-def render_backward(u: dict, aux: dict, means, log_scales, quats, raw_opac, out_img, v_out):
-    """Returns dict of dense grads (+ compact-order intermediates)."""
+def render_backward(u: dict, aux: dict, means, log_scales, quats, raw_opac, out_img, v_out, f32_sums=False):
+    """Returns dict of dense grads (+ compact-order intermediates).  f32_sums: also sum in f32 (pixels in
+    tile order, a splat's tiles in ascending intersection order) instead of the order-free f64 sums."""
     means, log_scales, quats, raw_opac = _f32(means), _f32(log_scales), _f32(quats), _f32(raw_opac)
     out_img, v_out = _f32(out_img), _f32(v_out)
     n = means.shape[0]
@@ -253,9 +257,45 @@ def render_backward(u: dict, aux: dict, means, log_scales, quats, raw_opac, out_
         setattr(s, k, aux[k].ctypes.data)
     s.max_intersects = int(aux["max_intersects"])
     us = _to_struct(u, n)
-    lib().oracle_render_backward(C.byref(us), C.byref(s), _p(means), _p(log_scales), _p(quats),
-                                 _p(raw_opac), C.c_uint32(n), _p(out_img), _p(v_out), _p(g["v_means"]),
-                                 _p(g["v_xy"]), _p(g["v_scales"]), _p(g["v_quats"]), _p(g["v_sh"]),
-                                 _p(g["v_opac"]), _p(g["v_xy_local"]), _p(g["v_conics"]),
-                                 _p(g["v_colors"]))
+    lib().oracle_render_backward_ex(C.byref(us), C.byref(s), _p(means), _p(log_scales), _p(quats),
+                                    _p(raw_opac), C.c_uint32(n), _p(out_img), _p(v_out), _p(g["v_means"]),
+                                    _p(g["v_xy"]), _p(g["v_scales"]), _p(g["v_quats"]), _p(g["v_sh"]),
+                                    _p(g["v_opac"]), _p(g["v_xy_local"]), _p(g["v_conics"]),
+                                    _p(g["v_colors"]), C.c_int(1 if f32_sums else 0))
+    return g
+
+
+def render_backward_f64(u: dict, aux: dict, means, log_scales, quats, raw_opac, out_img, v_out):
+    """The f64 arbiter (brush_oracle_f64.c): same inputs / forward state, every value in double, the walk's
+    decisions as the f32 restatement takes them.  Returns float64 dense grads and, under "mag_<name>", the sum of
+    the magnitudes of the terms each element is made of (|f32 result - exact| <= eps_per_term * mag) and, under
+    "flip_<name>", what the threshold decisions within f32 rounding of flipping can move."""
+    means, log_scales, quats, raw_opac = _f32(means), _f32(log_scales), _f32(quats), _f32(raw_opac)
+    out_img, v_out = _f32(out_img), _f32(v_out)
+    n = means.shape[0]
+    ncoef = (int(u["sh_degree"]) + 1) ** 2
+    g = {
+        "v_means": np.zeros((n, 3), np.float64), "v_xy": np.zeros((n, 2), np.float64),
+        "v_scales": np.zeros((n, 3), np.float64), "v_quats": np.zeros((n, 4), np.float64),
+        "v_sh": np.zeros((n, ncoef, 3), np.float64), "v_opac": np.zeros((n,), np.float64),
+    }
+    for k in list(g):
+        g["mag_" + k[2:]] = np.zeros_like(g[k])
+        g["flip_" + k[2:]] = np.zeros_like(g[k])
+    for k in ("means", "scales", "quats"):
+        g["vjp_" + k] = np.zeros_like(g["v_" + k])
+    s = _Aux()
+    for k in ("projected_splats", "num_intersections", "num_visible", "final_index", "cum_tiles_hit",
+              "tile_bins", "compact_gid_from_isect", "global_from_compact_gid"):
+        setattr(s, k, aux[k].ctypes.data)
+    s.max_intersects = int(aux["max_intersects"])
+    us = _to_struct(u, n)
+    lib().oracle_render_backward_f64(C.byref(us), C.byref(s), _p(means), _p(log_scales), _p(quats), _p(raw_opac),
+                                     C.c_uint32(n), _p(out_img), _p(v_out), _p(g["v_means"]), _p(g["v_xy"]),
+                                     _p(g["v_scales"]), _p(g["v_quats"]), _p(g["v_sh"]), _p(g["v_opac"]),
+                                     _p(g["mag_means"]), _p(g["mag_xy"]), _p(g["mag_scales"]), _p(g["mag_quats"]),
+                                     _p(g["mag_sh"]), _p(g["mag_opac"]),
+                                     _p(g["flip_means"]), _p(g["flip_xy"]), _p(g["flip_scales"]), _p(g["flip_quats"]),
+                                     _p(g["flip_sh"]), _p(g["flip_opac"]),
+                                     _p(g["vjp_means"]), _p(g["vjp_scales"]), _p(g["vjp_quats"]))
     return g

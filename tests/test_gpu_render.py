@@ -16,6 +16,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 PIX_TOL = 1e-4  # north-star tolerance on pixels (L-inf)
+EPS32 = 2.0 ** -24  # f32 unit round-off
 
 
 @pytest.fixture(scope="module")
@@ -141,10 +142,38 @@ def _run_pair(dev, cloud, w, h, sh_degree, max_intersects=None, v_out=None, came
     shared_aux["final_index"] = _np_u32(aux.final_index)
     o_g_shared = O.render_backward(u, shared_aux, cloud["means"], cloud["log_scales"], cloud["quats"],
                                    cloud["raw_opac"], g_out, v_out)
+    # The same shared forward state through (a) the oracle with every sum in f32 as well (one admissible execution
+    # of the reference's own arithmetic) and (b) the f64 arbiter: how far each f32 result is from the exact value.
+    o_g_f32 = O.render_backward(u, shared_aux, cloud["means"], cloud["log_scales"], cloud["quats"],
+                                cloud["raw_opac"], g_out, v_out, f32_sums=True)
+    o_g_f64 = O.render_backward_f64(u, shared_aux, cloud["means"], cloud["log_scales"], cloud["quats"],
+                                    cloud["raw_opac"], g_out, v_out)
     gpu = dict(out=g_out, aux=aux, u=u,
                v_means=params["means"].grad, v_scales=params["log_scales"].grad, v_quats=params["quats"].grad,
                v_sh=params["sh"].grad, v_opac=params["raw_opac"].grad, v_xy=xy.grad)
-    return gpu, dict(out=o_out, aux=o_aux, grads=o_g, grads_shared=o_g_shared)
+    return gpu, dict(out=o_out, aux=o_aux, grads=o_g, grads_shared=o_g_shared, grads_f32=o_g_f32, grads_f64=o_g_f64)
+
+
+def _arbiter_report(gpu, orc, tag=""):
+    """|gpu - f64| next to |oracle_f32 - f64| per gradient tensor (max and rms, in units of the tensor's scale)."""
+    rep = {}
+    for name in ("v_means", "v_scales", "v_quats", "v_sh", "v_opac", "v_xy"):
+        t = orc["grads_f64"][name]
+        a = gpu[name].detach().cpu().numpy().astype(np.float64).reshape(t.shape)
+        r = orc["grads_f32"][name].astype(np.float64).reshape(t.shape)
+        sc = np.abs(t).max() + 1e-300
+        eg, er = np.abs(a - t), np.abs(r - t)
+        rep[name] = dict(scale=sc, gpu_max=eg.max() / sc, gpu_rms=np.sqrt((eg ** 2).mean()) / sc,
+                         ref_max=er.max() / sc, ref_rms=np.sqrt((er ** 2).mean()) / sc)
+        mag = orc["grads_f64"]["mag_" + name[2:]]
+        nz = mag > 0
+        unit = EPS32 * mag[nz]
+        rep[name].update(gpu_units=float((eg[nz] / unit).max()) if nz.any() else 0.0,
+                         ref_units=float((er[nz] / unit).max()) if nz.any() else 0.0)
+        print(f"[arbiter {tag}] {name}: scale {sc:.3e}  gpu max {rep[name]['gpu_max']:.2e} rms {rep[name]['gpu_rms']:.2e}"
+              f"  | oracle-f32 max {rep[name]['ref_max']:.2e} rms {rep[name]['ref_rms']:.2e}"
+              f"  | in eps*mag units: gpu {rep[name]['gpu_units']:.1f} oracle-f32 {rep[name]['ref_units']:.1f}")
+    return rep
 
 
 def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0):
@@ -190,33 +219,62 @@ def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0):
     return V, I
 
 
-def _assert_grad_parity(gpu, orc, rtol=2e-4, direct_atol_frac=2e-5):
-    """GPU (f32 lane/wave sums + f32 atomics, unspecified order) vs the oracle (f64 tile sums).
+# Gradient tolerance, element by element, every term tied to a mechanism (no "fraction of the tensor's maximum"):
+#   |gpu - f64| <= RTOL |f64|                      the reference's own rtol (render.rs:815-830)
+#                + C_TERM eps32 mag               mag = sum of the MAGNITUDES of the per-pixel terms the element is
+#                                                 made of (f64 arbiter, carried through |gather / projection VJP|):
+#                                                 a per-term relative accuracy of C_TERM eps32 = 4e-6, whatever the
+#                                                 summation order (v_exp_f32 + f32 exponent argument: ~5 eps per
+#                                                 alpha, amplified by alpha / (1 - alpha) <= 99 where T is
+#                                                 recovered by division, rasterize_backwards.wgsl:244-246)
+#                + C_FLIP flip                    what the threshold decisions that sit within f32 rounding of
+#                                                 flipping (alpha ~ 1/255, sigma ~ 0) can move (arbiter)
+#                + C_VJP eps32 vjp                v_means / v_scales / v_quats only: the rounding noise of the
+#                                                 projection VJP itself; vjp = the sum of the magnitudes of the terms
+#                                                 it adds up (terms of size scale^2 cancel in v_V = T^t v_cov T and in
+#                                                 the column dot products of v_scale), evaluated by the arbiter.  The
+#                                                 GPU runs the same expression trees (-ffp-contract=off) on inputs that
+#                                                 differ in the last bits, so its noise is a different sample of it.
+#                + C_REF rowmax|oracle_f32 - f64| the error the f32 restatement of the reference makes on this row
+RTOL, C_TERM, C_FLIP, C_VJP, C_REF = 1e-4, 64.0, 1.5, 16.0, 4.0
 
-    |a-b| <= rtol*|b| + atol_frac*max|b|, against two oracle runs:
-      * shared forward state (tight): v_sh / v_opac / v_xy are direct sums -> 2e-5 of the
-        tensor's scale; v_means / v_scales / v_quats pass ~1e-6-relative differences in v_conic
-        through the ill-conditioned cov2d->cov3d->quat VJP (cancellation across terms of size
-        scale^2) -> 2e-4 of the tensor's scale;
-      * the oracle's own forward state (end to end): 1e-3 of the scale (see _run_pair).
-    The reference's own test holds v_quats to 1e-1 and the rest to rtol 1e-4 (render.rs:815-830)."""
-    for name, key, atol_frac in (("v_means", "v_means", 2e-4), ("v_scales", "v_scales", 2e-4),
-                                 ("v_quats", "v_quats", 2e-4), ("v_sh", "v_sh", direct_atol_frac),
-                                 ("v_opac", "v_opac", direct_atol_frac), ("v_xy", "v_xy", direct_atol_frac)):
-        a = gpu[name].detach().cpu().numpy().astype(np.float64)
-        e2e = orc["grads"][key].astype(np.float64).reshape(a.shape)
+
+def _assert_grad_parity(gpu, orc, tag=""):
+    """GPU gradients against the f64 arbiter fed with the forward state the GPU backward consumed; plus a loose
+    end-to-end check against the oracle's own forward state (T_final = 1 - out.a amplification, see _run_pair)
+    and exact zeros off the visible set."""
+    V = int(orc["aux"]["num_visible"][0])
+    f64 = orc["grads_f64"]
+    worst = {}
+    for name in ("v_means", "v_scales", "v_quats", "v_sh", "v_opac", "v_xy"):
+        t = f64[name]
+        a = gpu[name].detach().cpu().numpy().astype(np.float64).reshape(t.shape)
+        n = t.shape[0]
+        mag, flip = f64["mag_" + name[2:]], f64["flip_" + name[2:]]
+        ref_err = np.abs(orc["grads_f32"][name].astype(np.float64).reshape(t.shape) - t)
+        row_ref = ref_err.reshape(n, -1).max(axis=1).reshape((n,) + (1,) * (t.ndim - 1)) if n else ref_err
+        vjp = f64.get("vjp_" + name[2:], 0.0)
+        tol = RTOL * np.abs(t) + C_TERM * EPS32 * mag + C_FLIP * flip + C_VJP * EPS32 * vjp + C_REF * row_ref + 1e-300
+        err = np.abs(a - t)
+        ratio = err / tol
+        i = int(np.argmax(ratio)) if ratio.size else 0
+        worst[name] = float(ratio.reshape(-1)[i]) if ratio.size else 0.0
+        if ratio.size:
+            parts = [float(np.broadcast_to(x, t.shape).reshape(-1)[i]) for x in
+                     (RTOL * np.abs(t), C_TERM * EPS32 * mag, C_FLIP * flip, C_VJP * EPS32 * vjp, C_REF * row_ref)]
+            print(f"[grad {tag}] {name}: worst err/tol {worst[name]:.3f} (err {err.reshape(-1)[i]:.3e}; tol parts rtol "
+                  f"{parts[0]:.2e} term {parts[1]:.2e} flip {parts[2]:.2e} vjp {parts[3]:.2e} ref {parts[4]:.2e}); "
+                  f"elements with a flip allowance: {int((flip > 0).sum())}")
+        assert (err <= tol).all(), f"{name}: worst err/tol {worst[name]:.3f}, {(err > tol).sum()} elements over"
+        # end to end (oracle forward state): loose, the amplification is inherent to the reference's formulation
+        e2e = orc["grads"][name].astype(np.float64).reshape(a.shape)
         s2 = np.abs(e2e).max() + 1e-30
-        assert (np.abs(a - e2e) <= rtol * np.abs(e2e) + 1e-3 * s2).all(), f"{name} end-to-end"
-        b = orc["grads_shared"][key].astype(np.float64).reshape(a.shape)
-        scale = np.abs(b).max() + 1e-30
-        err = np.abs(a - b)
-        tol = rtol * np.abs(b) + atol_frac * scale
-        assert (err <= tol).all(), f"{name}: max err {err.max():.3e} scale {scale:.3e} bad {(err > tol).sum()}"
+        assert (np.abs(a - e2e) <= 2e-4 * np.abs(e2e) + 1e-3 * s2).all(), f"{name} end-to-end"
         # dense and exactly zero for non-visible splats
-        V = int(orc["aux"]["num_visible"][0])
         vis = np.zeros(a.shape[0], bool)
         vis[orc["aux"]["global_from_compact_gid"][:V]] = True
         assert not a[~vis].any()
+    return worst
 
 
 @pytest.mark.parametrize("n,w,h,deg,mult", [
@@ -233,7 +291,8 @@ def test_matches_oracle(dev, n, w, h, deg, mult):
     gpu, orc = _run_pair(dev, cloud, w, h, deg, max_intersects=4_000_000)
     V, I = _assert_forward_parity(gpu, orc, w, h)
     assert V > 0 and I > 0
-    _assert_grad_parity(gpu, orc)
+    _arbiter_report(gpu, orc, f"{n}@{w}x{h}")
+    _assert_grad_parity(gpu, orc, f"{n}@{w}x{h}")
 
 
 def test_rotated_off_centre_camera(dev):
@@ -376,7 +435,7 @@ def test_headline_size_matches_oracle(dev):
     assert V > 100000 and I > 400000
     # splats that cover the whole 120x68 tile grid sum 8160 float-atomic partials in unspecified order:
     # the direct sums get the same 2e-4 of the tensor's scale as the projected ones
-    _assert_grad_parity(gpu, orc, direct_atol_frac=2e-4)
+    _assert_grad_parity(gpu, orc)
 
 
 def _risk_report(orc, tag):
@@ -414,7 +473,7 @@ def test_c3_scale_raised_cap(dev, c3_cloud):
     V, I = _assert_forward_parity(gpu, orc, 1920, 1080)
     _risk_report(orc, "c3 raised cap")
     assert V > 300_000 and I >= 20_000_000 and int(gpu["aux"].overflow.item()) == 0
-    _assert_grad_parity(gpu, orc, direct_atol_frac=2e-4)
+    _assert_grad_parity(gpu, orc)
 
 
 def test_c3_scale_reference_cap_overflows(dev, c3_cloud):
@@ -425,7 +484,7 @@ def test_c3_scale_reference_cap_overflows(dev, c3_cloud):
     assert gpu["aux"].max_intersects == 128 * 65535
     V, I = _assert_forward_parity(gpu, orc, 1920, 1080)
     assert I == 8_388_480 and int(gpu["aux"].overflow.item()) == 1 and orc["aux"]["overflow"]
-    _assert_grad_parity(gpu, orc, direct_atol_frac=2e-4)
+    _assert_grad_parity(gpu, orc)
 
 
 def test_c5_scale_20m_splats_4k(dev):
@@ -437,7 +496,7 @@ def test_c5_scale_20m_splats_4k(dev):
     V, I = _assert_forward_parity(gpu, orc, 3840, 2160, saturation_flip_frac=1e-4)
     _risk_report(orc, "c5")
     assert V > 2_000_000 and I > 17_000_000 and int(gpu["aux"].overflow.item()) == 0
-    _assert_grad_parity(gpu, orc, direct_atol_frac=2e-4)
+    _assert_grad_parity(gpu, orc)
 
 
 def test_headline_size_properties(dev):
