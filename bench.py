@@ -6,8 +6,11 @@ rank per GPU over RCCL).  One "step" = one forward+backward pass of the hot path
 per GPU (BASELINE.json metric: fwd+bwd ms/view & iters/s, 1 M splats @1080p), on the seeded
 synthetic cloud of SURVEY §8(d) S1 (render_bench.rs:32-133 distribution, seed 4), inputs resident
 in HBM before the timed region.  For N>1 each rank renders its own view of the replicated cloud
-and the dense parameter-gradient block is all-reduced (RCCL) inside the step (SURVEY §8e);
-scaling is weak (per-GPU work fixed).  Rank 0 prints ONE JSON line.
+and the step ends with the SUM of the per-view parameter gradients on every rank: by
+default through an RCCL all-gather of 64-byte per-visible-splat records and a deterministic
+per-splat reduction (brush_amd/dist.py), with --dense-allreduce through one all-reduce of the dense
+block; scaling is weak (per-GPU work fixed).  Rank 0 prints ONE JSON line; `train` in it is the full
+training iteration (loss + Adam) at the same N.
 """
 from __future__ import annotations
 
@@ -25,7 +28,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-VALU_PEAK_GINST = 614.4  # wave64 VALU instructions/s: 256 CUs * 4 SIMDs * 2.4 GHz / 4 cycles
+VALU_PEAK_GINST = 923.9  # wave64 v_fma_f32/s: 256 CUs * 4 SIMDs * 2.4 GHz / 2.66 cycles (measured, tools/ubench)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
@@ -46,8 +49,9 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=20,
                     help="extra (untimed for `value`) steps of the full training iteration: loss + Adam groups")
     ap.add_argument("--dense-allreduce", action="store_true",
-                    help="N>1: all-reduce the dense 52+12C B/splat block instead of all-gathering the compact "
-                         "60 B/visible-splat records (brush_amd/dist.py)")
+                    help="N>1: all-reduce the dense 52+12C B/splat block instead of all-gathering the 64 B/visible-splat "
+                         "records (brush_amd/dist.py)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (dense scene, S3) of the N=1 line")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every launch from the host instead of replaying one captured hipGraph per step")
     return ap.parse_args()
@@ -144,62 +148,118 @@ def main():
     p = {k: torch.as_tensor(v, device=dev) for k, v in cloud.items()}
     cam = view_camera(rank, w, h)
     cap = args.max_intersects or None
-    # upstream gradient of mean(img) (render_bench.rs:180)
-    v_out = torch.full((h, w, 4), 1.0 / (4 * w * h), dtype=torch.float32, device=dev)
-    layout, total = R.grad_block_layout(n, C)
-    block = torch.zeros(total, dtype=torch.float32, device=dev)
-
-    def fwd_bwd():
-        out, aux, u = R._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"],
-                                      False, cap)
-        R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], C, out, v_out, block)
-        return aux
-
-    # The op never syncs, allocates or reads a count back, so one fwd+bwd is a capturable launch
-    # sequence: replaying it as a hipGraph removes the ~3.5 us/launch host enqueue cost
-    # (DESIGN.md "launch floor").  The all-reduce stays outside the graph.
-    graph = None
-    if not args.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fwd_bwd()  # warm allocator + code objects before capture
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            graph_aux = fwd_bwd()
-
-    def step():
-        if graph is not None:
-            graph.replay()
-            aux = graph_aux
-        else:
-            aux = fwd_bwd()
-        if world > 1:  # sum of the per-view gradients on every rank (RCCL over xGMI)
-            if args.dense_allreduce:
-                BD.allreduce_param_grads(block, n, C)
-            else:
-                BD.allreduce_param_grads_compact(block, aux, p["means"], n, C)
-        return aux
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        aux = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        aux = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def max_over_ranks(sec):
+        if world > 1:
+            t = torch.tensor([sec], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return sec
+
+    def timed(fn, steps, warmup):
+        """W untimed + K timed calls bracketed by barrier + synchronize on both sides, max over ranks."""
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    class Workload:
+        """One view of one cloud: forward (+ dense backward) as eager launches or as one replayed hipGraph."""
+
+        def __init__(self, pp, nn, ww, hh, camera, capacity):
+            self.p, self.n, self.w, self.h, self.cam, self.cap = pp, nn, ww, hh, camera, capacity
+            self.C = pp["sh"].shape[1]
+            # upstream gradient of mean(img) (render_bench.rs:180)
+            self.v_out = torch.full((hh, ww, 4), 1.0 / (4 * ww * hh), dtype=torch.float32, device=dev)
+            self.block = torch.zeros(R.grad_block_layout(nn, self.C)[1], dtype=torch.float32, device=dev)
+            self.graph = self.graph_fwd = None
+
+        def forward(self):
+            q = self.p
+            return R._forward_impl(self.cam, (self.w, self.h), q["means"], q["log_scales"], q["quats"], q["sh"],
+                                   q["raw_opac"], False, self.cap)
+
+        def fwd_bwd(self):
+            q = self.p
+            out, aux, u = self.forward()
+            R._backward_impl(u, aux, q["means"], q["log_scales"], q["quats"], q["raw_opac"], self.C, out, self.v_out,
+                             self.block)
+            return aux
+
+        def _capture(self, fn):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()  # warm allocator + code objects before capture
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                res = fn()
+            return g, res
+
+        def capture(self):
+            # The op never syncs, allocates or reads a count back, so one fwd+bwd is a capturable launch sequence:
+            # replaying it as a hipGraph removes the ~3.5 us/launch host enqueue cost (DESIGN.md "launch floor").
+            self.graph, self.graph_aux = self._capture(self.fwd_bwd)
+
+        def capture_forward(self):
+            self.graph_fwd, self.fwd_res = self._capture(self.forward)
+
+        def step(self):
+            if self.graph is not None:
+                self.graph.replay()
+                return self.graph_aux
+            return self.fwd_bwd()
+
+    wl = Workload(p, n, w, h, cam, cap)
+    exchange_mode = None
+    if world == 1:
+        if not args.no_graph:
+            wl.capture()
+        step = wl.step
+    elif args.dense_allreduce:
+        # the north-star's form: dense gradients, one all-reduce of the 52+12C B/splat block (RCCL over xGMI)
+        exchange_mode = "dense all-reduce of the [v_means|v_scales|v_quats|v_opac|v_sh] block"
+        if not args.no_graph:
+            wl.capture()
+
+        def step():
+            aux = wl.step()
+            BD.allreduce_param_grads(wl.block, n, C)
+            return aux
+    else:
+        # default: 64-byte records of the visible splats, all-gather, deterministic per-splat sum (brush_amd/dist.py)
+        exchange_mode = ("all-gather of 64-byte per-visible-splat gradient records + deterministic per-splat sum over "
+                         "views into the dense block (same sum on every rank, bit for bit)")
+        xchg = BD.ViewExchange(n, C, dev)
+        if not args.no_graph:
+            wl.capture_forward()
+
+        def step():
+            if wl.graph_fwd is not None:
+                wl.graph_fwd.replay()
+                out, aux, u = wl.fwd_res
+            else:
+                out, aux, u = wl.forward()
+            xchg.begin(aux)
+            xchg.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, wl.v_out)
+            xchg.gather()
+            xchg.reduce_dense(p["means"], wl.block)
+            return aux
+
+    elapsed = timed(step, args.steps, args.warmup)
+    aux = step()
+    torch.cuda.synchronize()
     ms_per_step = elapsed * 1e3 / args.steps
     value = n_gpus * args.steps / elapsed  # whole-job views/s
 
@@ -207,36 +267,46 @@ def main():
     overflow = int(aux.overflow.item())
     P, T = w * h, (-(-w // 16)) * (-(-h // 16))
 
+    # the same fwd+bwd as eager launches (host enqueue cost included), N=1 only
+    eager_ms = None
+    if world == 1 and wl.graph is not None:
+        eager_ms = timed(wl.fwd_bwd, args.steps, 2) * 1e3 / args.steps
+
     # ---- per-stage device time (hipEvents on the op's stream), separate untimed steps ----
     stage_ms = {}
     with StageProfiler() as prof:
         acc = None
         for _ in range(max(1, args.profile_steps)):
-            fwd_bwd()  # eager: events cannot be recorded inside a replayed graph
+            wl.fwd_bwd()  # eager: events cannot be recorded inside a replayed graph
             ms = prof.read_ms()
             acc = ms if acc is None else {k: acc[k] + ms[k] for k in ms}
         stage_ms = {k: v / max(1, args.profile_steps) for k, v in acc.items()}
     dominant = max(("rasterize", "rasterize_bwd", "project_bwd", "project_visible"), key=lambda k: stage_ms[k])
     dom_bytes = stage_bytes(dominant, n, V, I, P, T, C)
     achieved = dom_bytes / (stage_ms[dominant] * 1e-3) / 1e9 if stage_ms[dominant] > 0 else 0.0
-    traffic, valu = None, None
+    traffic, valu, traffic_src = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(dominant)
+            traffic_src = f"profiles/traffic.json ({tj.get('_tag', 'static')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not re-measured in this run"
             insts = tj.get("valu_insts", {}).get(dominant)
             if insts and stage_ms[dominant] > 0:
-                # The ceiling that actually binds the compositing kernels: one non-packed
-                # wave64 VALU instruction occupies a SIMD for 4 cycles -> 1024 SIMDs * 2.4 GHz / 4.
+                # The ceiling that binds the compositing kernels: VALU issue.  Measured with
+                # tools/ubench/valu_rate.hip: one v_fma_f32 per 2.66 SIMD cycles at 8 waves/SIMD.
                 rate = insts / (stage_ms[dominant] * 1e-3) / 1e9
                 valu = {"insts_per_launch": int(insts), "achieved_Ginst_s": round(rate, 1), "peak_Ginst_s": VALU_PEAK_GINST,
                         "frac": round(rate / VALU_PEAK_GINST, 4),
-                        "note": "SQ_INSTS_VALU per launch from profiles/ (rocprofv3 --pmc) / live kernel time"}
+                        # every VALU lane-op counted as one FMA (2 flop): an upper bound of the fraction of the
+                        # 157.3 TFLOP/s vector peak (SURVEY 8d asks for this figure)
+                        "valu_flops_frac_upper_bound": round(insts * 64 * 2 / (stage_ms[dominant] * 1e-3) / 157.3e12, 4),
+                        "note": "SQ_INSTS_VALU per launch from profiles/ (rocprofv3 --pmc) / live kernel time; peak = "
+                                "1024 SIMDs * 2.4 GHz / 2.66 cycles per v_fma_f32 (measured, profiles/r02a_valu_rate.txt)"}
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(stage_ms[dominant], 5), "valu_issue": valu}
     # Device-to-device copy bandwidth measured in the same run: 1 GiB read + 1 GiB write.
     src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
@@ -254,33 +324,70 @@ def main():
     B = algorithmic_bytes(n, V, I, P, T, C)
     whole_path = {"algorithmic_bytes": int(B), "achieved_GBs": round(B / (ms_per_step * 1e-3) / 1e9, 2),
                   "frac_of_hbm_peak": round(B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                  "measured_copy_GBs": round(copy_gbs, 1)}
+                  "measured_copy_GBs": round(copy_gbs, 1),
+                  "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4)}
 
-    # ---- full training iteration: render + L1/SSIM loss + backward + 5 Adam groups
+    # ---- full training iteration: render + L1/SSIM loss + backward + 5 Adam groups.
+    # N>1: one view per rank, records exchanged, every rank applies the same Adam update (train.rs:229-359 for a
+    # batch of N views); iters/s counts optimizer steps, views/s = N * iters/s.
     train = None
-    if args.train_steps > 0 and world == 1:  # secondary figure, single GPU only
+    if args.train_steps > 0:
         splats = brush_amd.Splats(p["means"], p["sh"], p["quats"], p["raw_opac"], p["log_scales"])
         trainer = brush_amd.SplatTrainer(splats, brush_amd.TrainConfig(warmup_steps=0, max_refine_step=0))
+        torch.manual_seed(1234 + rank)
         gt = torch.rand((h, w, 3), dtype=torch.float32, device=dev)  # synthetic target image
+        txchg = BD.ViewExchange(n, C, dev) if world > 1 else None
 
-        for _ in range(3):
-            trainer.step(splats, cam, gt, 1.0, 1, None)
-        barrier()
-        tt = time.perf_counter()
-        for _ in range(args.train_steps):
-            trainer.step(splats, cam, gt, 1.0, 1, None)
-        barrier()
-        tsec = time.perf_counter() - tt
-        if world > 1:
-            t = torch.tensor([tsec], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tsec = float(t.item())
+        def train_step():
+            trainer.step(splats, cam, gt, 1.0, world, None, txchg)
+
+        tsec = timed(train_step, args.train_steps, 3)
         train = {"iters_per_s": round(args.train_steps / tsec, 2), "ms_per_iter": round(tsec * 1e3 / args.train_steps, 4),
-                 "views_per_iter": n_gpus, "steps": args.train_steps,
+                 "views_per_iter": n_gpus, "views_per_s": round(n_gpus * args.train_steps / tsec, 2), "steps": args.train_steps,
                  "what": "render + L1*0.8-SSIM*0.2 loss + backward + 5 Adam groups (train.rs:211-359), no refinement, "
-                         "fused HIP loss kernels around the op, Adam inside the backward's last kernel (brush_l1_ssim_loss, "
-                         "brush_render_backward_adam)"}
+                         "fused HIP loss kernels around the op; " + (
+                             "Adam inside the backward's last kernel (brush_render_backward_adam)" if world == 1 else
+                             "per-view gradient records all-gathered (RCCL), summed per splat and fed straight into Adam "
+                             "(brush_reduce_view_records_adam), densification statistics inside the records")}
+        if world > 1:
+            # replicated parameters must stay replicated: compare a checksum of the updated parameters across ranks
+            chk = torch.stack([splats.means.detach().double().sum(), splats.sh_coeffs.detach().double().sum(),
+                               splats.rotation.detach().double().sum()])
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            train["parameters_identical_on_all_ranks"] = bool(torch.equal(lo, hi))
         del splats, trainer, gt
+
+    # ---- other named workloads (N=1): the dense scene and S3, short runs, reported as extra keys -------------
+    extra = None
+    if world == 1 and not args.no_extra:
+        extra = {}
+        todo = [("dense_scene", dict(n=n, w=w, h=h, deg=deg, mean_mult=0.25, cap=None, steps=20)),
+                ("S3", dict(n=20_971_520, w=3840, h=2160, deg=deg, mean_mult=1.0, cap=24_000_000, steps=6))]
+        if (n, w, h, args.mean_mult) != (1 << 20, 1920, 1080, 1.0):
+            todo = []
+        for name, c in todo:
+            try:
+                cl = synthetic_cloud(c["n"], c["deg"], mean_mult=c["mean_mult"])
+                pp = {k: torch.as_tensor(v, device=dev) for k, v in cl.items()}
+                del cl
+                x = Workload(pp, c["n"], c["w"], c["h"], view_camera(0, c["w"], c["h"]), c["cap"])
+                x.capture()
+                sec = timed(x.step, c["steps"], 2)
+                ax = x.step()
+                torch.cuda.synchronize()
+                Vx, Ix = ax.read_num_visible(), ax.read_num_intersections()
+                Px, Tx = c["w"] * c["h"], (-(-c["w"] // 16)) * (-(-c["h"] // 16))
+                Bx = algorithmic_bytes(c["n"], Vx, Ix, Px, Tx, (c["deg"] + 1) ** 2)
+                extra[name] = {"workload": f"{c['n']} splats @{c['w']}x{c['h']}, SH degree {c['deg']}, mean_mult {c['mean_mult']}",
+                               "ms_per_step": round(sec * 1e3 / c["steps"], 4), "num_visible": Vx, "num_intersections": Ix,
+                               "overflow": int(ax.overflow.item()), "algorithmic_bytes": int(Bx),
+                               "frac_of_hbm_peak": round(Bx / (sec / c["steps"]) / 1e9 / HBM_PEAK_GBS, 5)}
+                del x, pp, ax
+                torch.cuda.empty_cache()
+            except Exception as e:  # an extra line must never take the headline down
+                extra[name] = {"error": repr(e)}
 
     # ---- CPU baseline: the oracle (a port), rank 0, N=1 only --------------------------------
     cpu_baseline = None
@@ -288,7 +395,7 @@ def main():
         from oracle import oracle as O
 
         u_np = R.uniforms_to_numpy(aux)
-        v_np = v_out.cpu().numpy()
+        v_np = wl.v_out.cpu().numpy()
         reps = max(1, args.cpu_reps)
         tc = time.perf_counter()
         for _ in range(reps):
@@ -302,6 +409,9 @@ def main():
                                   f"algorithm, OpenMP; not wgpu/lavapipe), {cpu_s * 1e3:.0f} ms/view"}
 
     if rank == 0:
+        launch = "eager" if args.no_graph else (
+            "hipGraph replay of one fwd+bwd" if world == 1 or args.dense_allreduce else
+            "hipGraph replay of the forward; backward, all-gather and reduction enqueued per step")
         line = {
             "metric": "fwd+bwd views/s (train-iter rate of the rasterizer path), 1M splats @1080p",
             "value": round(value, 3), "unit": "views/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -310,14 +420,11 @@ def main():
             "config": {"workload": f"{'S1' if (n, w, h, deg, args.mean_mult) == (1 << 20, 1920, 1080, 3, 1.0) else 'custom'}: {n} splats @{w}x{h}, SH degree {deg}, seed 4, mean_mult {args.mean_mult}, "
                                    f"fwd+bwd per view", "views_per_step": n_gpus,
                        "parallelism": f"view-sharded dp{n_gpus}" if n_gpus > 1 else "single GPU",
-                       "gradient_exchange": None if n_gpus == 1 else (
-                           "dense all-reduce" if args.dense_allreduce else
-                           "all-gather of compact per-view records + local expansion (same dense sum)"),
-                       "launch": "eager" if graph is None else "hipGraph replay of one fwd+bwd",
+                       "gradient_exchange": exchange_mode, "launch": launch,
                        "num_visible": V, "num_intersections": I, "max_intersects": aux.max_intersects,
                        "overflow": overflow},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "whole_path": whole_path, "train": train,
-            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()}, "extra_workloads": extra,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

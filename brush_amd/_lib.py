@@ -90,10 +90,12 @@ _SYMBOLS = [
     ("brush_render_backward", C.c_int,
      [C.POINTER(BrushUniforms), C.POINTER(BrushAux), _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P,
       _P, _P, _P, C.c_size_t, _P]),
-    ("brush_pack_view_records", C.c_int,
-     [C.POINTER(BrushAux), C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_uint32, _P]),
-    ("brush_expand_view_records", C.c_int,
-     [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    ("brush_render_backward_records", C.c_int,
+     [C.POINTER(BrushUniforms), C.POINTER(BrushAux), _P, _P, _P, _P, C.c_uint32, _P, _P, _P, C.c_uint32, _P,
+      C.c_size_t, _P]),
+    ("brush_view_index_size", C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
+    ("brush_reduce_view_records", C.c_int,
+     [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     ("brush_loss_workspace_size", C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
     ("brush_l1_ssim_loss", C.c_int,
      [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_float, _P, _P, _P, C.c_size_t, _P]),
@@ -102,6 +104,9 @@ _SYMBOLS = [
     ("brush_render_backward_adam", C.c_int,
      [C.POINTER(BrushUniforms), C.POINTER(BrushAux), C.POINTER(BrushAdamConfig), _P, _P, _P, _P, _P, _P, C.c_uint32,
       _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    ("brush_reduce_view_records_adam", C.c_int,
+     [_P, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(BrushAdamConfig), C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P,
+      C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     ("brush_normalize_quats", C.c_int, [_P, _P, C.c_uint32, _P]),
     ("brush_refine_stats", C.c_int,
      [C.POINTER(BrushAux), _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),

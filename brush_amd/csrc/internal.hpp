@@ -61,6 +61,16 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
                                    float *v_means, float *v_xy,
                                    float *v_scales, float *v_quats, float *v_sh, float *v_opac,
                                    const AdamFuse *adam, hipStream_t s);
+// View-sharded data parallelism (project_bwd.hip): per-view 64-byte gradient records, their index by global id and
+// the deterministic per-splat sum over views (dense arrays, or straight into the Adam update when adam != nullptr).
+hipError_t launch_project_backward_records(const ViewParams &vp, const float *means, const float *log_scales,
+                                           const float *quats, const float *raw_opac, const uint32_t *num_visible,
+                                           const uint32_t *global_from_compact, const float *v_compact,
+                                           float *records, uint32_t max_rows, hipStream_t s);
+hipError_t launch_reduce_view_records(const float *records, uint32_t num_views, uint32_t rows_per_view,
+                                      const uint32_t *view_rows, const float *campos, const float *means, uint32_t n,
+                                      uint32_t sh_degree, uint32_t *index, float *v_means, float *v_scales,
+                                      float *v_quats, float *v_sh, float *v_opac, const AdamFuse *adam, hipStream_t s);
 hipError_t launch_zero_compact_grads(const uint32_t *num_visible, uint32_t n, float *v_compact, hipStream_t s);
 
 }  // namespace brush

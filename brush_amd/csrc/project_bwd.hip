@@ -69,6 +69,90 @@ __global__ __launch_bounds__(kThreads) void k_zero_compact_grads(const uint32_t 
         v_compact[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ProjectBackwards for one splat (project_backwards.wgsl:83-226): (v_xy, v_conic) -> v_mean, v_scale (log
+// space), v_quat.  Shared by the dense kernel, the per-view record kernel and nothing else.
+__device__ __forceinline__ void splat_projection_vjp(const ViewParams &vp, const float mean[3], const float scale[3],
+                                                     const float quat[4], const float vxy[2], const float vconic[3],
+                                                     float o_mean[3], float o_scale[3], float o_quat[4]) {
+    const Mat3 W = view_rot(vp);
+    float p_view[3];
+    to_view(vp, mean, p_view);
+    float vpj[3];
+    {  // project_pix_vjp :19-23
+        const float rw = 1.0f / (p_view[2] + 1e-6f);
+        const float vp0 = vp.focal[0] * vxy[0], vp1 = vp.focal[1] * vxy[1];
+        vpj[0] = vp0 * rw;
+        vpj[1] = vp1 * rw;
+        vpj[2] = -(vp0 * p_view[0] + vp1 * p_view[1]) * rw * rw;
+    }
+    float vm[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) vm[i] = W.m[0][i] * vpj[0] + W.m[1][i] * vpj[1] + W.m[2][i] * vpj[2];
+
+    float cov2d[3], conic[3], v_cov2d[3];
+    calc_cov2d(vp, p_view, scale, quat, cov2d);
+    cov_to_conic(cov2d, conic);
+    cov2d_to_conic_vjp(conic, vconic, v_cov2d);
+
+    const float rz = 1.0f / p_view[2];
+    const float rz2 = rz * rz;
+    // J from the UNCLAMPED p_view (project_backwards.wgsl:134-138)
+    Mat3 J;
+    J.m[0][0] = vp.focal[0] * rz; J.m[0][1] = 0.0f; J.m[0][2] = (-vp.focal[0]) * p_view[0] * rz2;
+    J.m[1][0] = 0.0f; J.m[1][1] = vp.focal[1] * rz; J.m[1][2] = (-vp.focal[1]) * p_view[1] * rz2;
+    J.m[2][0] = 0.0f; J.m[2][1] = 0.0f; J.m[2][2] = 0.0f;
+    const Mat3 R = quat_to_rotmat(quat);
+    Mat3 S;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) S.m[i][j] = (i == j) ? scale[i] : 0.0f;
+    const Mat3 M = mul(R, S);
+    const Mat3 V = mul(M, transpose(M));
+    Mat3 v_cov;
+    v_cov.m[0][0] = v_cov2d[0]; v_cov.m[0][1] = 0.5f * v_cov2d[1]; v_cov.m[0][2] = 0.0f;
+    v_cov.m[1][0] = 0.5f * v_cov2d[1]; v_cov.m[1][1] = v_cov2d[2]; v_cov.m[1][2] = 0.0f;
+    v_cov.m[2][0] = 0.0f; v_cov.m[2][1] = 0.0f; v_cov.m[2][2] = 0.0f;
+    const Mat3 T = mul(J, W);
+    const Mat3 Tt = transpose(T);
+    const Mat3 Vt = transpose(V);
+    const Mat3 v_V = mul(mul(Tt, v_cov), T);
+    const Mat3 v_T = add(mul(mul(v_cov, T), Vt), mul(mul(transpose(v_cov), T), V));
+
+    const float c0 = v_V.m[0][0];
+    const float c1 = v_V.m[1][0] + v_V.m[0][1];
+    const float c2 = v_V.m[2][0] + v_V.m[0][2];
+    const float c3 = v_V.m[1][1];
+    const float c4 = v_V.m[2][1] + v_V.m[1][2];
+    const float c5 = v_V.m[2][2];
+
+    const Mat3 v_J = mul(v_T, transpose(W));
+    const float rz3 = rz2 * rz;
+    const float vJ02 = v_J.m[0][2], vJ12 = v_J.m[1][2], vJ00 = v_J.m[0][0], vJ11 = v_J.m[1][1];
+    float v_t[3];
+    v_t[0] = (-vp.focal[0]) * rz2 * vJ02;
+    v_t[1] = (-vp.focal[1]) * rz2 * vJ12;
+    v_t[2] = (((-vp.focal[0]) * rz2 * vJ00 + 2.0f * vp.focal[0] * p_view[0] * rz3 * vJ02) -
+              vp.focal[1] * rz2 * vJ11) +
+             2.0f * vp.focal[1] * p_view[1] * rz3 * vJ12;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        o_mean[i] = vm[i] + ((v_t[0] * W.m[0][i] + v_t[1] * W.m[1][i]) + v_t[2] * W.m[2][i]);
+
+    Mat3 two_vVs;
+    two_vVs.m[0][0] = 2.0f * c0; two_vVs.m[0][1] = 2.0f * (0.5f * c1); two_vVs.m[0][2] = 2.0f * (0.5f * c2);
+    two_vVs.m[1][0] = 2.0f * (0.5f * c1); two_vVs.m[1][1] = 2.0f * c3; two_vVs.m[1][2] = 2.0f * (0.5f * c4);
+    two_vVs.m[2][0] = 2.0f * (0.5f * c2); two_vVs.m[2][1] = 2.0f * (0.5f * c4); two_vVs.m[2][2] = 2.0f * c5;
+    const Mat3 v_M = mul(two_vVs, M);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float vs = (R.m[0][j] * v_M.m[0][j] + R.m[1][j] * v_M.m[1][j]) + R.m[2][j] * v_M.m[2][j];
+        o_scale[j] = vs * scale[j];  // log-space (:219)
+    }
+    const Mat3 v_R = mul(v_M, S);
+    quat_to_rotmat_vjp(quat, v_R, o_quat);
+}
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 // Streaming 16-byte accesses: data that is touched once per step and is far larger than the caches.
 __device__ __forceinline__ float4 nt_load4(const float *p) {
@@ -100,6 +184,140 @@ __device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4
     nt_store4(a.m1 + e, m);
     nt_store4(a.m2 + e, v);
     return r;
+}
+
+// Last phase of the backward for the 64 splats [g0, g0+64) of one wave: the lane that owns splat g0+lane holds its
+// parameter gradients; they are either stored (dense arrays, every element written once, coalesced through the
+// per-wave LDS staging rows) or, ADAM, sent straight through the optimizer update of their parameter.
+// `stage`: kStageFloats of LDS private to the wave.
+template <int DEG, bool ADAM, bool ROWS_READY>
+__device__ __forceinline__ void store_gradients_or_step(
+    const AdamFuse &af, uint32_t n, uint32_t g0, uint32_t lane, float *stage, const float o_mean[3],
+    const float o_scale[3], const float o_quat[4], float o_opac, const float o_xy[2], float stat_norm,
+    float stat_count, const float *Y, const float vcol[3], float *__restrict__ v_means, float *__restrict__ v_xy,
+    float *__restrict__ v_scales, float *__restrict__ v_quats, float *__restrict__ v_sh, float *__restrict__ v_opac) {
+    constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
+    constexpr uint32_t kRow = ncoef * 3;     // floats per v_sh row
+    constexpr uint32_t kRowPad = kRow | 1u;  // odd LDS row stride: conflict-free column access
+    const uint32_t g_own = g0 + lane;
+    const bool in_range = g_own < n;
+    const uint32_t rows = min(kWave, n - g0);  // rows this wave owns (64 except at the tail)
+    const size_t nn = n;
+    if (in_range) {
+        if (v_xy) reinterpret_cast<float2 *>(v_xy)[g_own] = make_float2(o_xy[0], o_xy[1]);
+        if (!ADAM) {
+            reinterpret_cast<float4 *>(v_quats)[g_own] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
+            v_opac[g_own] = o_opac;
+        } else {
+            // rotation: the op was fed rot/|rot| (gaussian_splats.rs:174-175); chain v_q to the raw parameter
+            float4 r = reinterpret_cast<const float4 *>(af.rotation)[g_own];
+            float4 gq = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
+            if (af.quat_vjp) {
+                const float s2 = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+                const float inv_s = 1.0f / sqrtf(s2);
+                const float dot = (gq.x * r.x + gq.y * r.y + gq.z * r.z + gq.w * r.w) * (inv_s * inv_s * inv_s);
+                gq = make_float4(gq.x * inv_s - r.x * dot, gq.y * inv_s - r.y * dot, gq.z * inv_s - r.z * dot,
+                                 gq.w * inv_s - r.w * dot);
+            }
+            const size_t e = 6 * nn + (size_t)g_own * 4;
+            if (af.vec_ok) {
+                r = adam_elem4(af, e, gq, r, af.lr[2]);
+            } else {
+                r.x = adam_elem(af, e + 0, gq.x, r.x, af.lr[2]);
+                r.y = adam_elem(af, e + 1, gq.y, r.y, af.lr[2]);
+                r.z = adam_elem(af, e + 2, gq.z, r.z, af.lr[2]);
+                r.w = adam_elem(af, e + 3, gq.w, r.w, af.lr[2]);
+            }
+            reinterpret_cast<float4 *>(af.rotation)[g_own] = r;
+            if (af.norm_rot_out) {  // what the next forward will be fed (gaussian_splats.rs:174-175)
+                const float s = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+                reinterpret_cast<float4 *>(af.norm_rot_out)[g_own] = make_float4(r.x / s, r.y / s, r.z / s, r.w / s);
+            }
+            if (af.grad_2d_accum) {  // train.rs:284-316
+                af.grad_2d_accum[g_own] += stat_norm;
+                if (stat_count != 0.0f) af.xy_grad_counts[g_own] += stat_count;
+            }
+            af.raw_opac[g_own] = adam_elem(af, 10 * nn + g_own, o_opac, af.raw_opac[g_own], af.lr[3]);
+        }
+    }
+
+    // Copies `rows` rows of ROWF floats (row r at stage[r*STRIDE]) to dst, contiguous across lanes.
+    // ADAM: `dst` is the parameter array, `seg` the segment's offset in the moment arrays; the staged
+    // gradient updates the parameter in place (SH coefficients >= 1 with the lerp of train.rs:336-351).
+    auto copy_out = [&](float *dst, uint32_t rowf, uint32_t stride, size_t seg, float lr, bool is_sh) {
+        const uint32_t total = rows * rowf;  // floats; dst is 16-B aligned when g0*rowf % 4 == 0
+        auto one = [&](uint32_t f) {
+            const float gv = stage[(f / rowf) * stride + (f % rowf)];
+            if (!ADAM) {
+                dst[f] = gv;
+            } else {
+                const float x = dst[f];
+                const float st = adam_elem(af, seg + f, gv, x, lr);
+                dst[f] = (is_sh && (f % rowf) >= 3) ? x * (1.0f - af.sh_lerp) + st * af.sh_lerp : st;
+            }
+        };
+        if (((rowf & 3u) == 0 || rows == kWave) && (!ADAM || af.vec_ok)) {
+            // float4 path: rowf*64 is a multiple of 4 and the wave's base offset is 16-B aligned
+            for (uint32_t j = lane * 4; j < total; j += kWave * 4) {
+                if (j + 4 <= total) {
+                    float4 v;
+                    float *e = reinterpret_cast<float *>(&v);
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) {
+                        const uint32_t f = j + i;
+                        e[i] = stage[(f / rowf) * stride + (f % rowf)];
+                    }
+                    if (!ADAM) {
+                        nt_store4(dst + j, v);  // write-once stream
+                    } else {
+                        const float4 x = nt_load4(dst + j);
+                        float4 st = adam_elem4(af, seg + j, v, x, lr);
+                        if (is_sh) {
+                            const uint32_t k0 = j % rowf;  // position in the SH row; rows are rowf floats
+                            st.x = (k0 + 0) % rowf >= 3 ? x.x * (1.0f - af.sh_lerp) + st.x * af.sh_lerp : st.x;
+                            st.y = (k0 + 1) % rowf >= 3 ? x.y * (1.0f - af.sh_lerp) + st.y * af.sh_lerp : st.y;
+                            st.z = (k0 + 2) % rowf >= 3 ? x.z * (1.0f - af.sh_lerp) + st.z * af.sh_lerp : st.z;
+                            st.w = (k0 + 3) % rowf >= 3 ? x.w * (1.0f - af.sh_lerp) + st.w * af.sh_lerp : st.w;
+                        }
+                        nt_store4(dst + j, st);
+                    }
+                } else {
+                    for (uint32_t f = j; f < total; f++) one(f);
+                }
+            }
+        } else {
+            for (uint32_t f = lane; f < total; f += kWave) one(f);
+        }
+    };
+
+    // v_sh: row = Y[k] * v_rgb (ROWS_READY: the caller has already summed the rows of several views in `stage`)
+    {
+        if (!ROWS_READY) {
+            float *row = stage + lane * kRowPad;
+#pragma unroll
+            for (uint32_t k = 0; k < ncoef; k++) {
+                row[k * 3 + 0] = Y[k] * vcol[0];
+                row[k * 3 + 1] = Y[k] * vcol[1];
+                row[k * 3 + 2] = Y[k] * vcol[2];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        copy_out((ADAM ? af.sh : v_sh) + (size_t)g0 * kRow, kRow, kRowPad, 11 * nn + (size_t)g0 * kRow, af.lr[4], true);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // v_means, v_scales: 3 floats per row
+    {
+        stage[lane * 4 + 0] = o_mean[0];
+        stage[lane * 4 + 1] = o_mean[1];
+        stage[lane * 4 + 2] = o_mean[2];
+        stage[256 + lane * 4 + 0] = o_scale[0];
+        stage[256 + lane * 4 + 1] = o_scale[1];
+        stage[256 + lane * 4 + 2] = o_scale[2];
+        __builtin_amdgcn_wave_barrier();
+        copy_out((ADAM ? af.means : v_means) + (size_t)g0 * 3, 3, 4, (size_t)g0 * 3, af.lr[0], false);
+        stage += 256;
+        copy_out((ADAM ? af.log_scales : v_scales) + (size_t)g0 * 3, 3, 4, 3 * nn + (size_t)g0 * 3, af.lr[1], false);
+    }
 }
 
 // ADAM: instead of storing the dense parameter gradients, every element goes straight through the
@@ -184,83 +402,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
         o_xy[1] = vxy[1];
 
         // ---- ProjectBackwards (project_backwards.wgsl:83-226)
-        const Mat3 W = view_rot(vp);
-        float p_view[3];
-        to_view(vp, mean, p_view);
-        float vpj[3];
-        {  // project_pix_vjp :19-23
-            const float rw = 1.0f / (p_view[2] + 1e-6f);
-            const float vp0 = vp.focal[0] * vxy[0], vp1 = vp.focal[1] * vxy[1];
-            vpj[0] = vp0 * rw;
-            vpj[1] = vp1 * rw;
-            vpj[2] = -(vp0 * p_view[0] + vp1 * p_view[1]) * rw * rw;
-        }
-        float vm[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) vm[i] = W.m[0][i] * vpj[0] + W.m[1][i] * vpj[1] + W.m[2][i] * vpj[2];
-
-        float cov2d[3], conic[3], v_cov2d[3];
-        calc_cov2d(vp, p_view, scale, quat, cov2d);
-        cov_to_conic(cov2d, conic);
-        cov2d_to_conic_vjp(conic, vconic, v_cov2d);
-
-        const float rz = 1.0f / p_view[2];
-        const float rz2 = rz * rz;
-        // J from the UNCLAMPED p_view (project_backwards.wgsl:134-138)
-        Mat3 J;
-        J.m[0][0] = vp.focal[0] * rz; J.m[0][1] = 0.0f; J.m[0][2] = (-vp.focal[0]) * p_view[0] * rz2;
-        J.m[1][0] = 0.0f; J.m[1][1] = vp.focal[1] * rz; J.m[1][2] = (-vp.focal[1]) * p_view[1] * rz2;
-        J.m[2][0] = 0.0f; J.m[2][1] = 0.0f; J.m[2][2] = 0.0f;
-        const Mat3 R = quat_to_rotmat(quat);
-        Mat3 S;
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) S.m[i][j] = (i == j) ? scale[i] : 0.0f;
-        const Mat3 M = mul(R, S);
-        const Mat3 V = mul(M, transpose(M));
-        Mat3 v_cov;
-        v_cov.m[0][0] = v_cov2d[0]; v_cov.m[0][1] = 0.5f * v_cov2d[1]; v_cov.m[0][2] = 0.0f;
-        v_cov.m[1][0] = 0.5f * v_cov2d[1]; v_cov.m[1][1] = v_cov2d[2]; v_cov.m[1][2] = 0.0f;
-        v_cov.m[2][0] = 0.0f; v_cov.m[2][1] = 0.0f; v_cov.m[2][2] = 0.0f;
-        const Mat3 T = mul(J, W);
-        const Mat3 Tt = transpose(T);
-        const Mat3 Vt = transpose(V);
-        const Mat3 v_V = mul(mul(Tt, v_cov), T);
-        const Mat3 v_T = add(mul(mul(v_cov, T), Vt), mul(mul(transpose(v_cov), T), V));
-
-        const float c0 = v_V.m[0][0];
-        const float c1 = v_V.m[1][0] + v_V.m[0][1];
-        const float c2 = v_V.m[2][0] + v_V.m[0][2];
-        const float c3 = v_V.m[1][1];
-        const float c4 = v_V.m[2][1] + v_V.m[1][2];
-        const float c5 = v_V.m[2][2];
-
-        const Mat3 v_J = mul(v_T, transpose(W));
-        const float rz3 = rz2 * rz;
-        const float vJ02 = v_J.m[0][2], vJ12 = v_J.m[1][2], vJ00 = v_J.m[0][0], vJ11 = v_J.m[1][1];
-        float v_t[3];
-        v_t[0] = (-vp.focal[0]) * rz2 * vJ02;
-        v_t[1] = (-vp.focal[1]) * rz2 * vJ12;
-        v_t[2] = (((-vp.focal[0]) * rz2 * vJ00 + 2.0f * vp.focal[0] * p_view[0] * rz3 * vJ02) -
-                  vp.focal[1] * rz2 * vJ11) +
-                 2.0f * vp.focal[1] * p_view[1] * rz3 * vJ12;
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-            o_mean[i] = vm[i] + ((v_t[0] * W.m[0][i] + v_t[1] * W.m[1][i]) + v_t[2] * W.m[2][i]);
-
-        Mat3 two_vVs;
-        two_vVs.m[0][0] = 2.0f * c0; two_vVs.m[0][1] = 2.0f * (0.5f * c1); two_vVs.m[0][2] = 2.0f * (0.5f * c2);
-        two_vVs.m[1][0] = 2.0f * (0.5f * c1); two_vVs.m[1][1] = 2.0f * c3; two_vVs.m[1][2] = 2.0f * (0.5f * c4);
-        two_vVs.m[2][0] = 2.0f * (0.5f * c2); two_vVs.m[2][1] = 2.0f * (0.5f * c4); two_vVs.m[2][2] = 2.0f * c5;
-        const Mat3 v_M = mul(two_vVs, M);
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const float vs = (R.m[0][j] * v_M.m[0][j] + R.m[1][j] * v_M.m[1][j]) + R.m[2][j] * v_M.m[2][j];
-            o_scale[j] = vs * scale[j];  // log-space (:219)
-        }
-        const Mat3 v_R = mul(v_M, S);
-        quat_to_rotmat_vjp(quat, v_R, o_quat);
+        splat_projection_vjp(vp, mean, scale, quat, vxy, vconic, o_mean, o_scale, o_quat);
 
         float *r = res + li * kRes;  // hand the results to the lane that owns splat `li`
         r[0] = o_mean[0], r[1] = o_mean[1], r[2] = o_mean[2];
@@ -285,122 +427,128 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     }
     __syncthreads();  // `res` aliases the store staging below
     if (g0 >= n) return;  // wave-uniform; past the last barrier
-    const uint32_t rows = min(kWave, n - g0);  // rows this wave owns (64 except at the tail)
-    const size_t nn = n;
-    if (in_range) {
-        reinterpret_cast<float2 *>(v_xy)[g_own] = make_float2(o_xy[0], o_xy[1]);
-        if (!ADAM) {
-            reinterpret_cast<float4 *>(v_quats)[g_own] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
-            v_opac[g_own] = o_opac;
-        } else {
-            // rotation: the op was fed rot/|rot| (gaussian_splats.rs:174-175); chain v_q to the raw parameter
-            float4 r = reinterpret_cast<const float4 *>(af.rotation)[g_own];
-            float4 gq = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
-            if (af.quat_vjp) {
-                const float s2 = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
-                const float inv_s = 1.0f / sqrtf(s2);
-                const float dot = (gq.x * r.x + gq.y * r.y + gq.z * r.z + gq.w * r.w) * (inv_s * inv_s * inv_s);
-                gq = make_float4(gq.x * inv_s - r.x * dot, gq.y * inv_s - r.y * dot, gq.z * inv_s - r.z * dot,
-                                 gq.w * inv_s - r.w * dot);
-            }
-            const size_t e = 6 * nn + (size_t)g_own * 4;
-            if (af.vec_ok) {
-                r = adam_elem4(af, e, gq, r, af.lr[2]);
-            } else {
-                r.x = adam_elem(af, e + 0, gq.x, r.x, af.lr[2]);
-                r.y = adam_elem(af, e + 1, gq.y, r.y, af.lr[2]);
-                r.z = adam_elem(af, e + 2, gq.z, r.z, af.lr[2]);
-                r.w = adam_elem(af, e + 3, gq.w, r.w, af.lr[2]);
-            }
-            reinterpret_cast<float4 *>(af.rotation)[g_own] = r;
-            if (af.norm_rot_out) {  // what the next forward will be fed (gaussian_splats.rs:174-175)
-                const float s = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
-                reinterpret_cast<float4 *>(af.norm_rot_out)[g_own] = make_float4(r.x / s, r.y / s, r.z / s, r.w / s);
-            }
-            if (af.grad_2d_accum) {  // train.rs:284-316
-                const float vx = o_xy[0] * af.half_w, vy = o_xy[1] * af.half_h;
-                af.grad_2d_accum[g_own] += sqrtf(vx * vx + vy * vy);
-                if (c_own != kInvalid) af.xy_grad_counts[g_own] += 1.0f;
-            }
-            af.raw_opac[g_own] = adam_elem(af, 10 * nn + g_own, o_opac, af.raw_opac[g_own], af.lr[3]);
-        }
+    float stat_norm = 0.0f;
+    if (ADAM && af.grad_2d_accum) {  // train.rs:300-302
+        const float vx = o_xy[0] * af.half_w, vy = o_xy[1] * af.half_h;
+        stat_norm = sqrtf(vx * vx + vy * vy);
     }
+    store_gradients_or_step<DEG, ADAM, false>(af, n, g0, lane, stage, o_mean, o_scale, o_quat, o_opac, o_xy, stat_norm,
+                                              c_own != kInvalid ? 1.0f : 0.0f, Y, vcol, v_means, v_xy, v_scales, v_quats,
+                                              v_sh, v_opac);
+}
 
-    // Copies `rows` rows of ROWF floats (row r at stage[r*STRIDE]) to dst, contiguous across lanes.
-    // ADAM: `dst` is the parameter array, `seg` the segment's offset in the moment arrays; the staged
-    // gradient updates the parameter in place (SH coefficients >= 1 with the lerp of train.rs:336-351).
-    auto copy_out = [&](float *dst, uint32_t rowf, uint32_t stride, size_t seg, float lr, bool is_sh) {
-        const uint32_t total = rows * rowf;  // floats; dst is 16-B aligned when g0*rowf % 4 == 0
-        auto one = [&](uint32_t f) {
-            const float gv = stage[(f / rowf) * stride + (f % rowf)];
-            if (!ADAM) {
-                dst[f] = gv;
-            } else {
-                const float x = dst[f];
-                const float st = adam_elem(af, seg + f, gv, x, lr);
-                dst[f] = (is_sh && (f % rowf) >= 3) ? x * (1.0f - af.sh_lerp) + st * af.sh_lerp : st;
-            }
-        };
-        if (((rowf & 3u) == 0 || rows == kWave) && (!ADAM || af.vec_ok)) {
-            // float4 path: rowf*64 is a multiple of 4 and the wave's base offset is 16-B aligned
-            for (uint32_t j = lane * 4; j < total; j += kWave * 4) {
-                if (j + 4 <= total) {
-                    float4 v;
-                    float *e = reinterpret_cast<float *>(&v);
-#pragma unroll
-                    for (uint32_t i = 0; i < 4; i++) {
-                        const uint32_t f = j + i;
-                        e[i] = stage[(f / rowf) * stride + (f % rowf)];
-                    }
-                    if (!ADAM) {
-                        nt_store4(dst + j, v);  // write-once stream
-                    } else {
-                        const float4 x = nt_load4(dst + j);
-                        float4 st = adam_elem4(af, seg + j, v, x, lr);
-                        if (is_sh) {
-                            const uint32_t k0 = j % rowf;  // position in the SH row; rows are rowf floats
-                            st.x = (k0 + 0) % rowf >= 3 ? x.x * (1.0f - af.sh_lerp) + st.x * af.sh_lerp : st.x;
-                            st.y = (k0 + 1) % rowf >= 3 ? x.y * (1.0f - af.sh_lerp) + st.y * af.sh_lerp : st.y;
-                            st.z = (k0 + 2) % rowf >= 3 ? x.z * (1.0f - af.sh_lerp) + st.z * af.sh_lerp : st.z;
-                            st.w = (k0 + 3) % rowf >= 3 ? x.w * (1.0f - af.sh_lerp) + st.w * af.sh_lerp : st.w;
-                        }
-                        nt_store4(dst + j, st);
-                    }
-                } else {
-                    for (uint32_t f = j; f < total; f++) one(f);
-                }
-            }
-        } else {
-            for (uint32_t f = lane; f < total; f += kWave) one(f);
-        }
-    };
+// ---- view-sharded data parallelism: per-view gradient records and their deterministic reduction ------------
+//
+// A view's parameter gradient is non-zero only for its visible splats and its SH row is rank one,
+// v_sh[g] = Y(dir_view(g)) (x) v_rgb[g] (gather_grads.wgsl:186-222): 16 floats per VISIBLE splat describe it,
+//   [gid | v_means(3) | v_scales(3) | v_quats(4) | v_opac | v_rgb(3) | |v_xy * (w/2, h/2)|]          (64 bytes)
+// k_project_backward_records writes them in compact (depth) order straight from the compositing backward's sums
+// (no dense 52+12C bytes/splat arrays at all); the ranks all-gather the records of every view and
+// k_reduce_view_records, one lane per GLOBAL splat id, adds the <= W records of its splat in view order 0..W-1.
+// No atomics: the sum is the same bit pattern on every rank and from run to run, so replicated parameters stay
+// replicated.  The sums go through store_gradients_or_step: dense arrays, or straight into the Adam update.
 
-    // v_sh: row = Y[k] * v_rgb
-    {
-        float *row = stage + lane * kRowPad;
+constexpr uint32_t kRecFloats = 16;
+
+__global__ __launch_bounds__(kThreads) void k_project_backward_records(
+    ViewParams vp, const float *__restrict__ means, const float *__restrict__ log_scales,
+    const float *__restrict__ quats, const float *__restrict__ raw_opac, const uint32_t *__restrict__ num_visible,
+    const uint32_t *__restrict__ global_from_compact, const float *__restrict__ v_compact,
+    float4 *__restrict__ records, uint32_t max_rows, float half_w, float half_h) {
+    const uint32_t V = min(min(*num_visible, vp.total_splats), max_rows);
+    for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < V; c += gridDim.x * kThreads) {
+        const uint32_t g = global_from_compact[c];
+        const float4 *row = reinterpret_cast<const float4 *>(v_compact) + (size_t)c * (kCompactStride / 4);
+        const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+        const float vxy[2] = {r0.x, r0.y};
+        const float vconic[3] = {r0.z, r0.w, r1.x};
+        const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
+        const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
+                                det_expf(log_scales[(size_t)g * 3 + 2])};
+        const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
+        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float sg = det_sigmoid(raw_opac[g]);
+        const float o_opac = r2.x * (sg * (1.0f - sg));  // gather_grads.wgsl:224-227
+        float o_mean[3], o_scale[3], o_quat[4];
+        splat_projection_vjp(vp, mean, scale, quat, vxy, vconic, o_mean, o_scale, o_quat);
+        const float vx = vxy[0] * half_w, vy = vxy[1] * half_h;  // train.rs:300-302
+        float4 *out = records + (size_t)c * (kRecFloats / 4);
+        out[0] = make_float4(__uint_as_float(g), o_mean[0], o_mean[1], o_mean[2]);
+        out[1] = make_float4(o_scale[0], o_scale[1], o_scale[2], o_quat[0]);
+        out[2] = make_float4(o_quat[1], o_quat[2], o_quat[3], o_opac);
+        out[3] = make_float4(r1.y, r1.z, r1.w, sqrtf(vx * vx + vy * vy));
+    }
+}
+
+// index[v * n + gid] = row of splat gid in view v's records.  Never reset: a reader validates an entry by
+// checking row < view_rows[v] and records[v][row].gid == gid (a gid appears at most once per view), so stale
+// entries of earlier steps are harmless.
+__global__ __launch_bounds__(kThreads) void k_build_view_index(const float4 *__restrict__ records, uint32_t num_views,
+                                                               uint32_t rows_per_view,
+                                                               const uint32_t *__restrict__ view_rows, uint32_t n,
+                                                               uint32_t *__restrict__ index) {
+    const uint32_t total = num_views * rows_per_view;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < total; i += gridDim.x * kThreads) {
+        const uint32_t v = i / rows_per_view, r = i - v * rows_per_view;
+        if (r >= view_rows[v]) continue;
+        const uint32_t gid = __float_as_uint(records[(size_t)i * (kRecFloats / 4)].x);
+        if (gid < n) index[(size_t)v * n + gid] = r;
+    }
+}
+
+template <int DEG, bool ADAM>
+__global__ __launch_bounds__(kThreads) void k_reduce_view_records(
+    const float4 *__restrict__ records, uint32_t num_views, uint32_t rows_per_view,
+    const uint32_t *__restrict__ view_rows, const float *__restrict__ campos, const uint32_t *__restrict__ index,
+    const float *means, uint32_t n, float *__restrict__ v_means, float *__restrict__ v_scales,
+    float *__restrict__ v_quats, float *__restrict__ v_sh, float *__restrict__ v_opac, AdamFuse af) {
+    constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
+    constexpr uint32_t kRow = ncoef * 3, kRowPad = kRow | 1u;
+    constexpr uint32_t kStageFloats = (kWave * kRowPad > 512u ? kWave * kRowPad : 512u);
+    __shared__ float stage_all[kThreads / kWave][kStageFloats];
+    const uint32_t wv = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    float *stage = stage_all[wv];
+    const uint32_t g0 = blockIdx.x * kThreads + wv * kWave;
+    if (g0 >= n) return;  // wave-uniform; the kernel has no workgroup barrier
+    const uint32_t g = g0 + lane;
+    float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_quat[4] = {0.f, 0.f, 0.f, 0.f};
+    float o_opac = 0.f, stat_norm = 0.f, stat_count = 0.f;
+    float *row = stage + lane * kRowPad;
 #pragma unroll
-        for (uint32_t k = 0; k < ncoef; k++) {
-            row[k * 3 + 0] = Y[k] * vcol[0];
-            row[k * 3 + 1] = Y[k] * vcol[1];
-            row[k * 3 + 2] = Y[k] * vcol[2];
+    for (uint32_t k = 0; k < kRow; k++) row[k] = 0.f;
+    if (g < n) {
+        const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
+        for (uint32_t v = 0; v < num_views; v++) {  // fixed order: the same bits on every rank
+            const uint32_t r = index[(size_t)v * n + g];
+            if (r >= min(view_rows[v], rows_per_view)) continue;
+            const float4 *rec = records + ((size_t)v * rows_per_view + r) * (kRecFloats / 4);
+            const float4 a = rec[0];
+            if (__float_as_uint(a.x) != g) continue;  // stale index entry
+            const float4 b = rec[1], c = rec[2], d = rec[3];
+            o_mean[0] += a.y, o_mean[1] += a.z, o_mean[2] += a.w;
+            o_scale[0] += b.x, o_scale[1] += b.y, o_scale[2] += b.z;
+            o_quat[0] += b.w, o_quat[1] += c.x, o_quat[2] += c.y, o_quat[3] += c.z;
+            o_opac += c.w;
+            stat_norm += d.w;
+            stat_count += 1.0f;
+            // gather_grads.wgsl:182-222 with this view's camera term (viewmat[3].xyz)
+            float dir[3] = {mean[0] - campos[v * 3], mean[1] - campos[v * 3 + 1], mean[2] - campos[v * 3 + 2]};
+            const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            dir[0] = dir[0] / len, dir[1] = dir[1] / len, dir[2] = dir[2] / len;
+            float Y[ncoef];
+            sh_basis<ncoef>(DEG, dir, Y);
+#pragma unroll
+            for (uint32_t k = 0; k < ncoef; k++) {
+                row[k * 3 + 0] += Y[k] * d.x;
+                row[k * 3 + 1] += Y[k] * d.y;
+                row[k * 3 + 2] += Y[k] * d.z;
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        copy_out((ADAM ? af.sh : v_sh) + (size_t)g0 * kRow, kRow, kRowPad, 11 * nn + (size_t)g0 * kRow, af.lr[4], true);
-        __builtin_amdgcn_wave_barrier();
     }
-    // v_means, v_scales: 3 floats per row
-    {
-        stage[lane * 4 + 0] = o_mean[0];
-        stage[lane * 4 + 1] = o_mean[1];
-        stage[lane * 4 + 2] = o_mean[2];
-        stage[256 + lane * 4 + 0] = o_scale[0];
-        stage[256 + lane * 4 + 1] = o_scale[1];
-        stage[256 + lane * 4 + 2] = o_scale[2];
-        __builtin_amdgcn_wave_barrier();
-        copy_out((ADAM ? af.means : v_means) + (size_t)g0 * 3, 3, 4, (size_t)g0 * 3, af.lr[0], false);
-        stage += 256;
-        copy_out((ADAM ? af.log_scales : v_scales) + (size_t)g0 * 3, 3, 4, 3 * nn + (size_t)g0 * 3, af.lr[1], false);
-    }
+    const float zero2[2] = {0.f, 0.f}, zero3[3] = {0.f, 0.f, 0.f};
+    store_gradients_or_step<DEG, ADAM, true>(af, n, g0, lane, stage, o_mean, o_scale, o_quat, o_opac, zero2, stat_norm,
+                                             stat_count, nullptr, zero3, v_means, nullptr, v_scales, v_quats, v_sh,
+                                             v_opac);
 }
 
 }  // namespace
@@ -438,6 +586,49 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
         default: BRUSH_LAUNCH_PB(4); break;
     }
 #undef BRUSH_LAUNCH_PB
+    return hipGetLastError();
+}
+
+hipError_t launch_project_backward_records(const ViewParams &vp, const float *means, const float *log_scales,
+                                           const float *quats, const float *raw_opac, const uint32_t *num_visible,
+                                           const uint32_t *global_from_compact, const float *v_compact,
+                                           float *records, uint32_t max_rows, hipStream_t s) {
+    if (vp.total_splats == 0 || max_rows == 0) return hipSuccess;
+    const uint32_t rows = min(vp.total_splats, max_rows);
+    hipLaunchKernelGGL(k_project_backward_records, dim3(min(ceil_div(rows, kThreads), 2048u)), dim3(kThreads), 0, s, vp,
+                       means, log_scales, quats, raw_opac, num_visible, global_from_compact, v_compact,
+                       reinterpret_cast<float4 *>(records), max_rows, (float)vp.img_size[0] / 2.0f,
+                       (float)vp.img_size[1] / 2.0f);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_view_records(const float *records, uint32_t num_views, uint32_t rows_per_view,
+                                      const uint32_t *view_rows, const float *campos, const float *means, uint32_t n,
+                                      uint32_t sh_degree, uint32_t *index, float *v_means, float *v_scales,
+                                      float *v_quats, float *v_sh, float *v_opac, const AdamFuse *adam, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const float4 *rec4 = reinterpret_cast<const float4 *>(records);
+    if (num_views * rows_per_view > 0)
+        hipLaunchKernelGGL(k_build_view_index, dim3(min(ceil_div(num_views * rows_per_view, kThreads), 2048u)),
+                           dim3(kThreads), 0, s, rec4, num_views, rows_per_view, view_rows, n, index);
+    const dim3 grid(ceil_div(n, kThreads)), block(kThreads);
+    AdamFuse af{};
+    if (adam) af = *adam;
+#define BRUSH_LAUNCH_RV(D)                                                                                         \
+    if (adam)                                                                                                      \
+        hipLaunchKernelGGL((k_reduce_view_records<D, true>), grid, block, 0, s, rec4, num_views, rows_per_view,    \
+                           view_rows, campos, index, means, n, v_means, v_scales, v_quats, v_sh, v_opac, af);      \
+    else                                                                                                           \
+        hipLaunchKernelGGL((k_reduce_view_records<D, false>), grid, block, 0, s, rec4, num_views, rows_per_view,   \
+                           view_rows, campos, index, means, n, v_means, v_scales, v_quats, v_sh, v_opac, af)
+    switch (sh_degree) {
+        case 0: BRUSH_LAUNCH_RV(0); break;
+        case 1: BRUSH_LAUNCH_RV(1); break;
+        case 2: BRUSH_LAUNCH_RV(2); break;
+        case 3: BRUSH_LAUNCH_RV(3); break;
+        default: BRUSH_LAUNCH_RV(4); break;
+    }
+#undef BRUSH_LAUNCH_RV
     return hipGetLastError();
 }
 

@@ -281,6 +281,34 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
     return BRUSH_OK;
 }
 
+// Shared by the fused backward+Adam forms: validates the optimizer arguments and fills the kernel-side struct.
+static bool fill_adam_fuse(const BrushAdamConfig *cfg, float *means, float *log_scales, float *rotation,
+                           float *raw_opacity, float *sh, uint32_t n, float *moment1, float *moment2,
+                           float *next_quats_fed, float *grad_2d_accum, float *xy_grad_counts, uint32_t w, uint32_t h,
+                           AdamFuse *out) {
+    if (!cfg || cfg->time == 0) return false;
+    if (n > 0 && (!means || !log_scales || !rotation || !raw_opacity || !sh || !moment1 || !moment2)) return false;
+    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!aligned(rotation) || (next_quats_fed && !aligned(next_quats_fed))) return false;
+    if ((grad_2d_accum == nullptr) != (xy_grad_counts == nullptr)) return false;
+    AdamFuse af{};
+    af.means = means, af.log_scales = log_scales, af.rotation = rotation, af.raw_opac = raw_opacity, af.sh = sh;
+    af.m1 = moment1, af.m2 = moment2;
+    af.lr[0] = cfg->lr_mean, af.lr[1] = cfg->lr_scale, af.lr[2] = cfg->lr_rotation, af.lr[3] = cfg->lr_opac;
+    af.lr[4] = cfg->lr_coeffs_dc;
+    af.sh_lerp = cfg->sh_rest_lerp, af.beta1 = cfg->beta1, af.beta2 = cfg->beta2, af.eps = cfg->epsilon;
+    af.bc1 = 1.0f - powf(cfg->beta1, (float)cfg->time);
+    af.bc2 = 1.0f - powf(cfg->beta2, (float)cfg->time);
+    af.quat_vjp = cfg->rotation_grad_wrt_normalized;
+    af.norm_rot_out = next_quats_fed;
+    af.grad_2d_accum = grad_2d_accum, af.xy_grad_counts = xy_grad_counts;
+    af.half_w = (float)w / 2.0f, af.half_h = (float)h / 2.0f;
+    af.vec_ok = (n % 4 == 0) && aligned(means) && aligned(log_scales) && aligned(sh) && aligned(moment1) &&
+                aligned(moment2);
+    *out = af;
+    return true;
+}
+
 extern "C" int brush_render_backward(const BrushUniforms *h_uniforms, const BrushAux *h_aux, const float *means,
                                      const float *log_scales, const float *quats, const float *raw_opacity,
                                      uint32_t n, const float *out_img, const float *v_out, float *v_means,
@@ -298,28 +326,93 @@ extern "C" int brush_render_backward_adam(const BrushUniforms *h_uniforms, const
                                           float *grad_2d_accum, float *xy_grad_counts, void *workspace,
                                           size_t workspace_bytes, brush_stream_t stream) {
     if (!cfg || cfg->time == 0 || !h_uniforms || h_uniforms->sh_degree > 4) return BRUSH_ERR_INVALID_ARG;
-    if (n > 0 && (!rotation || !sh || !moment1 || !moment2)) return BRUSH_ERR_INVALID_ARG;
-    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (!aligned(rotation) || !aligned(quats_fed)) return BRUSH_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(quats_fed) & 15) != 0) return BRUSH_ERR_INVALID_ARG;
     AdamFuse af{};
-    af.means = means, af.log_scales = log_scales, af.rotation = rotation, af.raw_opac = raw_opacity, af.sh = sh;
-    af.m1 = moment1, af.m2 = moment2;
-    af.lr[0] = cfg->lr_mean, af.lr[1] = cfg->lr_scale, af.lr[2] = cfg->lr_rotation, af.lr[3] = cfg->lr_opac;
-    af.lr[4] = cfg->lr_coeffs_dc;
-    af.sh_lerp = cfg->sh_rest_lerp, af.beta1 = cfg->beta1, af.beta2 = cfg->beta2, af.eps = cfg->epsilon;
-    af.bc1 = 1.0f - powf(cfg->beta1, (float)cfg->time);
-    af.bc2 = 1.0f - powf(cfg->beta2, (float)cfg->time);
-    af.quat_vjp = cfg->rotation_grad_wrt_normalized;
-    if (next_quats_fed && !aligned(next_quats_fed)) return BRUSH_ERR_INVALID_ARG;
-    if ((grad_2d_accum == nullptr) != (xy_grad_counts == nullptr)) return BRUSH_ERR_INVALID_ARG;
-    af.norm_rot_out = next_quats_fed;
-    af.grad_2d_accum = grad_2d_accum, af.xy_grad_counts = xy_grad_counts;
-    af.half_w = (float)h_uniforms->img_size[0] / 2.0f, af.half_h = (float)h_uniforms->img_size[1] / 2.0f;
-    af.vec_ok = (n % 4 == 0) && aligned(means) && aligned(log_scales) && aligned(sh) && aligned(moment1) &&
-                aligned(moment2);
+    if (!fill_adam_fuse(cfg, means, log_scales, rotation, raw_opacity, sh, n, moment1, moment2, next_quats_fed,
+                        grad_2d_accum, xy_grad_counts, h_uniforms->img_size[0], h_uniforms->img_size[1], &af))
+        return BRUSH_ERR_INVALID_ARG;
     return render_backward_impl(h_uniforms, h_aux, means, log_scales, quats_fed, raw_opacity, n, out_img, v_out,
                                 nullptr, v_xy, nullptr, nullptr, nullptr, nullptr, &af, workspace, workspace_bytes,
                                 stream);
+}
+
+// ---- view-sharded data parallelism (build extension) ------------------------------------------
+
+extern "C" int brush_render_backward_records(const BrushUniforms *h_uniforms, const BrushAux *h_aux, const float *means,
+                                             const float *log_scales, const float *quats, const float *raw_opacity,
+                                             uint32_t n, const float *out_img, const float *v_out, float *records,
+                                             uint32_t max_rows, void *workspace, size_t workspace_bytes,
+                                             brush_stream_t stream) {
+    if (!uniforms_ok(h_uniforms) || !aux_ok(h_aux, true) || !out_img || !v_out || !workspace)
+        return BRUSH_ERR_INVALID_ARG;
+    if (n > 0 && (!means || !log_scales || !quats || !raw_opacity || (max_rows > 0 && !records)))
+        return BRUSH_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(records) & 15) != 0) return BRUSH_ERR_INVALID_ARG;
+    const BrushAux &aux = *h_aux;
+    const BwdWs ws = carve_bwd(workspace, n);
+    if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    BrushUniforms u = *h_uniforms;
+    u.total_splats = n;
+    const ViewParams vp = make_view_params(u, n);
+    mark_bwd(s, 0);
+    BRUSH_HIP_CHECK(launch_zero_compact_grads(aux.num_visible, n, ws.v_compact, s));
+    mark_bwd(s, 1);
+    BRUSH_HIP_CHECK(launch_rasterize_backward(u.img_size[0], u.img_size[1], u.tile_bounds[0], u.tile_bounds[1],
+                                              aux.compact_gid_from_isect, aux.tile_bins, aux.projected_splats,
+                                              aux.final_index, out_img, v_out, ws.v_compact, s));
+    mark_bwd(s, 2);
+    BRUSH_HIP_CHECK(launch_project_backward_records(vp, means, log_scales, quats, raw_opacity, aux.num_visible,
+                                                    aux.global_from_compact_gid, ws.v_compact, records, max_rows, s));
+    mark_bwd(s, 3);
+    return BRUSH_OK;
+}
+
+extern "C" int brush_view_index_size(uint32_t n, uint32_t num_views, size_t *bytes) {
+    if (!bytes) return BRUSH_ERR_INVALID_ARG;
+    *bytes = sizeof(uint32_t) * (size_t)(n ? n : 1) * (num_views ? num_views : 1);
+    return BRUSH_OK;
+}
+
+static int reduce_views_impl(const float *records, uint32_t num_views, uint32_t rows_per_view, const uint32_t *view_rows,
+                             const float *campos, const float *means, uint32_t n, uint32_t sh_degree, float *v_means,
+                             float *v_scales, float *v_quats, float *v_sh, float *v_opac, const AdamFuse *adam,
+                             void *view_index, size_t view_index_bytes, brush_stream_t stream) {
+    if (sh_degree > 4 || num_views == 0) return BRUSH_ERR_INVALID_ARG;
+    if (n == 0) return BRUSH_OK;
+    if (!means || !view_index || !view_rows || !campos || (rows_per_view > 0 && !records)) return BRUSH_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(records) & 15) != 0) return BRUSH_ERR_INVALID_ARG;
+    if (!adam && (!v_means || !v_scales || !v_quats || !v_sh || !v_opac)) return BRUSH_ERR_INVALID_ARG;
+    if (view_index_bytes < sizeof(uint32_t) * (size_t)n * num_views) return BRUSH_ERR_WORKSPACE_SMALL;
+    if ((uint64_t)num_views * rows_per_view > 0xFFFFFFFFull) return BRUSH_ERR_INVALID_ARG;
+    BRUSH_HIP_CHECK(launch_reduce_view_records(records, num_views, rows_per_view, view_rows, campos, means, n, sh_degree,
+                                               static_cast<uint32_t *>(view_index), v_means, v_scales, v_quats, v_sh,
+                                               v_opac, adam, static_cast<hipStream_t>(stream)));
+    return BRUSH_OK;
+}
+
+extern "C" int brush_reduce_view_records(const float *records, uint32_t num_views, uint32_t rows_per_view,
+                                         const uint32_t *view_rows, const float *campos, const float *means,
+                                         uint32_t n, uint32_t sh_degree, float *v_means, float *v_scales,
+                                         float *v_quats, float *v_sh, float *v_opac, void *view_index,
+                                         size_t view_index_bytes, brush_stream_t stream) {
+    return reduce_views_impl(records, num_views, rows_per_view, view_rows, campos, means, n, sh_degree, v_means,
+                             v_scales, v_quats, v_sh, v_opac, nullptr, view_index, view_index_bytes, stream);
+}
+
+extern "C" int brush_reduce_view_records_adam(const float *records, uint32_t num_views, uint32_t rows_per_view,
+                                              const uint32_t *view_rows, const float *campos,
+                                              const BrushAdamConfig *cfg, uint32_t width, uint32_t height,
+                                              float *means, float *log_scales, float *rotation, float *raw_opacity,
+                                              float *sh, uint32_t n, uint32_t sh_degree, float *moment1, float *moment2,
+                                              float *next_quats_fed, float *grad_2d_accum, float *xy_grad_counts,
+                                              void *view_index, size_t view_index_bytes, brush_stream_t stream) {
+    AdamFuse af{};
+    if (!fill_adam_fuse(cfg, means, log_scales, rotation, raw_opacity, sh, n, moment1, moment2, next_quats_fed,
+                        grad_2d_accum, xy_grad_counts, width, height, &af))
+        return BRUSH_ERR_INVALID_ARG;
+    return reduce_views_impl(records, num_views, rows_per_view, view_rows, campos, means, n, sh_degree, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, &af, view_index, view_index_bytes, stream);
 }
 
 // ---- opt-in stage timing ------------------------------------------------------------------

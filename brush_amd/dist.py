@@ -3,20 +3,21 @@ single-device, batch fixed to 1: crates/brush-train/src/train.rs:216-219).
 
 One process per GPU, splat parameters replicated, rank r renders view r of the batch.  The loss of
 the reference is a mean over the stacked batch (train.rs:239-268), so B-view data parallelism is
-the mean of per-view gradients: each rank scales its upstream gradient by 1/B (or averages after
-the reduce) and ONE all-reduce(sum) over the contiguous parameter-gradient prefix of the gradient
-block `[v_means|v_scales|v_quats|v_opac|v_sh]` (brush_amd.render.grad_block_layout) makes every
-rank hold the batch gradient.  The screen-space statistics the trainer keeps for densification
-(train.rs:284-316) are per view, so their *norms* and visibility counts are reduced separately in
-one small second message.
+the mean of per-view gradients: each rank scales its upstream gradient by 1/B and the step needs the
+SUM over views on every rank.  Two forms:
 
-xGMI is point-to-point (7 links/GPU): at N = 1 M, SH degree 3 the block is 247 MB, i.e.
-2*(7/8)*247 MB ≈ 432 MB per GPU through the ring; RCCL picks the algorithm, nothing here assumes
-a switch.
+  * `ViewExchange` (default): all-gather of 64-byte per-visible-splat records + one deterministic
+    reduction kernel (dense sum, or straight into Adam) — sized for xGMI, bit-identical on all ranks;
+  * `allreduce_param_grads`: ONE dense all-reduce(sum) over the contiguous parameter-gradient prefix
+    `[v_means|v_scales|v_quats|v_opac|v_sh]` of the gradient block (what the north-star describes).
+    xGMI is point-to-point (7 links/GPU): at N = 1 M, SH degree 3 that block is 247 MB, i.e.
+    2*(7/8)*247 MB ≈ 432 MB per GPU through a ring; RCCL picks the algorithm, nothing here assumes a switch.
+
+The screen-space statistics the trainer keeps for densification (train.rs:284-316) are per view: their
+norms and visibility counts travel inside the records (or, with the dense form, in one small second message).
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
@@ -44,28 +45,34 @@ def allreduce_param_grads(block: torch.Tensor, n: int, ncoef: int, average: bool
 
 
 # --------------------------------------------------------------------------------------------
-# Compact gradient exchange
+# Exchange of per-view gradient records (the default N>1 path)
 #
 # One view touches ~10 % of the splats and its SH gradient row is rank one,
 # v_sh[g] = Y(dir_view(g)) (x) v_rgb[g] (gather_grads.wgsl:186-222), so the view's whole parameter
-# gradient is described by 15 numbers per VISIBLE splat:
-#     gid | v_means(3) | v_scales(3) | v_quats(4) | v_opac | v_sh[g,0,:](3)      (60 bytes)
-# instead of 52+12C bytes per splat (244 at SH degree 3).  Every rank all-gathers the records of
-# all views (RCCL all_gather, padded to the largest view) and expands + sums them locally into the
-# dense block; Y is recomputed from the replicated means and each view's camera term.  The result
-# on every rank is the same dense sum an all-reduce would give (up to f32 summation order and one
-# extra rounding in v_rgb = v_sh0 / Y0); the bytes on xGMI drop from ~2*(W-1)/W*247 MB to
-# (W-1)*6 MB per rank at N = 1 M, SH degree 3, which is what makes 2..8 GPUs scale when a view
-# takes only ~0.5 ms to render.
+# gradient is described by 16 floats per VISIBLE splat (include/brush_hip.h):
+#     gid | v_means(3) | v_scales(3) | v_quats(4) | v_opac | v_rgb(3) | |v_xy * (w/2, h/2)|      (64 bytes)
+# instead of 52+12C bytes per splat (244 at SH degree 3).  brush_render_backward_records writes them
+# straight from the compositing backward (no dense arrays), every rank all-gathers the records of all
+# views (RCCL all_gather, padded to the largest view), and ONE kernel over global splat ids sums the
+# <= W records of each splat in view order and either stores the dense sum (brush_reduce_view_records)
+# or feeds it straight into the Adam update (brush_reduce_view_records_adam).  No float atomics: every
+# rank computes the same bits from the same bytes, so the replicated parameters cannot drift apart
+# (what an unordered atomic expansion or a per-rank "own view exact, others approximate" scheme allows).
+# Bytes on xGMI per rank: (W-1) * 6.6 MB at N = 1 M, SH degree 3, vs ~2*(W-1)/W*247 MB for the dense all-reduce.
+#
+# Sizing without stalling the GPU: the per-view counts are known as soon as the FORWARD has projected the
+# splats.  `begin()` (called right after the forward is enqueued) all-gathers [num_visible | camera term] and
+# starts their copy to the host; the backward is enqueued with the records buffer's current capacity; by the
+# time the host asks for the counts (`counts()`), that copy finished long ago (the GPU is still busy with the
+# loss and the backward), so the exact-size all-gather is enqueued without the GPU ever idling.
 # --------------------------------------------------------------------------------------------
-_REC = 16  # floats per record (15 used, 64-byte rows)
-_SH_C0 = 0.2820947917738781
+_REC = 16  # floats per record
 
 
 def sh_basis_torch(degree: int, d: torch.Tensor) -> torch.Tensor:
     """Sloan basis of project_visible.wgsl:51-147 / gather_grads.wgsl:17-112 for unit dirs [M,3] -> [M,C]."""
     x, y, z = d[:, 0], d[:, 1], d[:, 2]
-    Y = [torch.full_like(x, _SH_C0)]
+    Y = [torch.full_like(x, 0.2820947917738781)]
     if degree >= 1:
         a = 0.48860251190292
         Y += [-a * y, a * z, -a * x]
@@ -101,191 +108,234 @@ def _seg_ptr(block, layout, name):
     return block.data_ptr() + layout[name][0] * 4
 
 
-def pack_view_records(block: torch.Tensor, aux: RenderAux, n: int, ncoef: int, rows: int) -> torch.Tensor:
-    """[rows, 16] f32 records of this view's visible splats through brush_pack_view_records (rows
-    beyond num_visible are left uninitialised; consumers use the per-view row counts)."""
-    import ctypes as C
-
-    from . import _lib
-
-    assert block.is_cuda, "brush_amd has no CPU path: tensors must live on the GPU"
-    layout, _ = grad_block_layout(n, ncoef)
-    rec = torch.empty((rows, _REC), dtype=torch.float32, device=block.device)
-    s = aux._as_struct()
-    degree = int(round(ncoef ** 0.5)) - 1
-    with torch.cuda.device(block.device):
-        stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().brush_pack_view_records(C.byref(s), n, degree, _seg_ptr(block, layout, "v_means"),
-                                                      _seg_ptr(block, layout, "v_scales"),
-                                                      _seg_ptr(block, layout, "v_quats"), _seg_ptr(block, layout, "v_opac"),
-                                                      _seg_ptr(block, layout, "v_sh"), rec.data_ptr(), rows, stream),
-                   "brush_pack_view_records")
-    return rec
-
-
-def pack_view_records_torch(block: torch.Tensor, aux: RenderAux, n: int, ncoef: int, rows: int) -> torch.Tensor:
-    """Plain-torch restatement of brush_pack_view_records (test reference; CPU gloo test)."""
-    layout, _ = grad_block_layout(n, ncoef)
-    dev = block.device
-    idx = torch.arange(rows, device=dev)
-    valid = idx < aux.num_visible.to(idx.dtype)
-    gid = torch.where(valid, aux.global_from_compact_gid[:n].long()[idx.clamp(max=max(n - 1, 0))], torch.zeros_like(idx))
-
-    def seg(name, width):
-        off, sz = layout[name]
-        return block[off:off + sz].view(n, width)
-
+def records_from_dense_torch(grads: dict, aux: RenderAux, n: int, img_size, rows: int) -> torch.Tensor:
+    """Plain-torch restatement of the record layout (test reference; CPU gloo test): builds the [rows,16]
+    records of a view from its DENSE gradients `grads` (v_means, v_scales, v_quats, v_opac, v_sh, v_xy):
+    v_rgb = v_sh[g,0,:] / Y0."""
+    dev = grads["v_means"].device
+    V = min(int(aux.num_visible.reshape(-1)[0]), rows)
+    gid = aux.global_from_compact_gid[:V].long()
     rec = torch.zeros((rows, _REC), dtype=torch.float32, device=dev)
-    rec[:, 0] = gid.to(torch.int32).view(torch.float32)
-    rec[:, 1:4] = seg("v_means", 3)[gid]
-    rec[:, 4:7] = seg("v_scales", 3)[gid]
-    rec[:, 7:11] = seg("v_quats", 4)[gid]
-    rec[:, 11] = seg("v_opac", 1)[gid, 0]
-    rec[:, 12:15] = seg("v_sh", ncoef * 3)[gid, 0:3]
-    rec[:, 15] = 1.0
+    rec[:V, 0] = gid.to(torch.int32).view(torch.float32)
+    rec[:V, 1:4] = grads["v_means"][gid]
+    rec[:V, 4:7] = grads["v_scales"][gid]
+    rec[:V, 7:11] = grads["v_quats"][gid]
+    rec[:V, 11] = grads["v_opac"][gid]
+    rec[:V, 12:15] = grads["v_sh"][gid, 0, :] / 0.2820947917738781
+    w, h = float(img_size[0]), float(img_size[1])
+    vxy = grads["v_xy"][gid]
+    rec[:V, 15] = torch.sqrt((vxy[:, 0] * (w / 2.0)) ** 2 + (vxy[:, 1] * (h / 2.0)) ** 2)
     return rec
 
 
-def expand_view_records(recs: torch.Tensor, view_rows: torch.Tensor, campos: torch.Tensor, means: torch.Tensor,
-                        block: torch.Tensor, n: int, ncoef: int, own_view: Optional[int] = None) -> torch.Tensor:
-    """Sums the records of the views (recs [W, rows, 16], valid rows per view `view_rows` int32 [W],
-    camera terms [W, 3] = viewmat[3].xyz of each view) into the parameter prefix of `block` with the
-    HIP kernel brush_expand_view_records.  own_view=None: the prefix is overwritten by the sum of
-    all W views; own_view=r: `block` already holds view r's dense gradients and the other views
-    are added on top.  Device tensors only (no CPU path)."""
-    from . import _lib
-
-    assert block.is_cuda and recs.is_cuda and means.is_cuda, "brush_amd has no CPU path: tensors must live on the GPU"
-    layout, _ = grad_block_layout(n, ncoef)
+def reduce_view_records_torch(recs: torch.Tensor, view_rows: torch.Tensor, campos: torch.Tensor, means: torch.Tensor,
+                              n: int, ncoef: int) -> dict:
+    """Plain-torch restatement of brush_reduce_view_records: dense sum over views, accumulated in view order
+    (every rank that runs this on the same bytes gets the same bits)."""
     W, rows, _ = recs.shape
-    recs, campos, means = recs.contiguous(), campos.contiguous(), means.contiguous()
-    view_rows = view_rows.to(torch.int32).contiguous()
+    dev = recs.device
     degree = int(round(ncoef ** 0.5)) - 1
-    with torch.cuda.device(block.device):
-        stream = torch.cuda.current_stream().cuda_stream
-        skip = 0xFFFFFFFF if own_view is None else int(own_view)
-        _lib.check(_lib.lib().brush_expand_view_records(recs.data_ptr(), W * rows, rows, view_rows.data_ptr(),
-                                                        campos.data_ptr(), means.data_ptr(), n, degree, skip,
-                                                        _seg_ptr(block, layout, "v_means"), _seg_ptr(block, layout, "v_scales"),
-                                                        _seg_ptr(block, layout, "v_quats"), _seg_ptr(block, layout, "v_opac"),
-                                                        _seg_ptr(block, layout, "v_sh"), stream),
-                   "brush_expand_view_records")
-    return block
+    out = {"v_means": torch.zeros((n, 3), device=dev), "v_scales": torch.zeros((n, 3), device=dev),
+           "v_quats": torch.zeros((n, 4), device=dev), "v_opac": torch.zeros((n,), device=dev),
+           "v_sh": torch.zeros((n, ncoef, 3), device=dev), "xy_norm": torch.zeros((n,), device=dev),
+           "views_seen": torch.zeros((n,), device=dev)}
+    for v in range(W):
+        cnt = min(int(view_rows[v]), rows)
+        r = recs[v, :cnt]
+        gid = r[:, 0].contiguous().view(torch.int32).long()
+        keep = (gid >= 0) & (gid < n)
+        r, gid = r[keep], gid[keep]
+        out["v_means"][gid] += r[:, 1:4]      # a gid appears at most once per view: plain indexed add
+        out["v_scales"][gid] += r[:, 4:7]
+        out["v_quats"][gid] += r[:, 7:11]
+        out["v_opac"][gid] += r[:, 11]
+        out["xy_norm"][gid] += r[:, 15]
+        out["views_seen"][gid] += 1.0
+        d = means[gid] - campos[v][None, :]
+        d = d / torch.sqrt(torch.sum(d * d, dim=1, keepdim=True))
+        Y = sh_basis_torch(degree, d)
+        out["v_sh"][gid] += Y[:, :, None] * r[:, None, 12:15]
+    return out
 
 
-def expand_view_records_torch(recs: torch.Tensor, view_rows: torch.Tensor, campos: torch.Tensor, means: torch.Tensor,
-                              block: torch.Tensor, n: int, ncoef: int, own_view: Optional[int] = None) -> torch.Tensor:
-    """Plain-torch restatement of brush_expand_view_records (test reference; CPU gloo test)."""
-    layout, _ = grad_block_layout(n, ncoef)
-    W, rows, _ = recs.shape
-    flat = recs.reshape(W * rows, _REC)
-    ridx = torch.arange(W * rows, device=flat.device)
-    view = ridx // rows
-    keep = (ridx - view * rows) < view_rows.to(ridx.dtype)[view]
-    if own_view is not None:
-        keep = keep & (view != own_view)
-    gid = flat[:, 0].contiguous().view(torch.int32).long()
-    gid = torch.where(keep, gid, torch.zeros_like(gid))
-    flat = torch.where(keep[:, None], flat, torch.zeros_like(flat))  # rows beyond a view's count are garbage
-    w = keep.to(torch.float32)[:, None]
-    cam = campos.repeat_interleave(rows, dim=0)
-    d = means[gid] - cam
-    d = d / torch.sqrt(torch.sum(d * d, dim=1, keepdim=True))
-    degree = int(round(ncoef ** 0.5)) - 1
-    Y = sh_basis_torch(degree, d)                        # [M, C]
-    rgb = flat[:, 12:15] * (w / _SH_C0)                  # v_rgb = v_sh0 / Y0 (0 for padding rows)
-    Y = torch.where(keep[:, None], Y, torch.zeros_like(Y))  # padding rows may have NaN dirs
-    if own_view is None:
-        block[:param_grad_floats(n, ncoef)].zero_()
-
-    def seg(name, width):
-        off, sz = layout[name]
-        return block[off:off + sz].view(n, width)
-
-    seg("v_means", 3).index_add_(0, gid, flat[:, 1:4] * w)
-    seg("v_scales", 3).index_add_(0, gid, flat[:, 4:7] * w)
-    seg("v_quats", 4).index_add_(0, gid, flat[:, 7:11] * w)
-    seg("v_opac", 1).index_add_(0, gid, flat[:, 11:12] * w)
-    seg("v_sh", ncoef * 3).index_add_(0, gid, (Y[:, :, None] * rgb[:, None, :]).reshape(-1, ncoef * 3))
-    return block
+def _padded_rows(count: int) -> int:
+    return max(256, -(-int(count) // 256) * 256)
 
 
-def _padded_rows(count: int, chunks: int = 1) -> int:
-    q = 256 * chunks
-    return max(q, -(-int(count) // q) * q)
+class ViewExchange:
+    """One view per rank: sizes, all-gathers and reduces the per-view gradient records of a step.
 
+        xchg = ViewExchange(n, ncoef, device)
+        ... enqueue forward ...
+        xchg.begin(aux)                               # counts + camera terms start travelling
+        ... enqueue loss ...
+        xchg.backward_records(u, aux, params..., out, v_out)   # compositing backward -> this view's records
+        xchg.gather()                                 # exact-size all-gather (host learns the counts here)
+        grads = xchg.reduce_dense(means)   or   xchg.reduce_adam(cfg, params..., moments...)
+    """
 
-# rows used by the previous exchange of the same (group, cloud size), with headroom: lets the next
-# exchange be enqueued before the host has seen the new counts (they are all-gathered, hence the
-# same on every rank, so every rank sizes its collectives identically).
-_ROWS_HINT = {}
+    def __init__(self, n: int, ncoef: int, device, group: Optional[dist.ProcessGroup] = None):
+        self.n, self.ncoef, self.device, self.group = int(n), int(ncoef), torch.device(device), group
+        self.degree = int(round(ncoef ** 0.5)) - 1
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if live else 1
+        self.rank = dist.get_rank(group) if live else 0
+        self.capacity = 0          # rows of the local records buffer
+        self.local = None          # [capacity, 16]
+        self.gathered = None       # [world * capacity * 16] backing store of the all-gather result
+        self.index = None          # brush_view_index_size bytes
+        self.metas = torch.empty((self.world, 4), dtype=torch.int32, device=self.device)
+        self._host = None
+        self._event = None
+        self._counts_host = None
+        self._rows = 0
+        self.regrown = 0           # how often a view outgrew the buffer after the backward was enqueued
 
+    # -- sizing ------------------------------------------------------------------------------
+    def begin(self, aux: RenderAux):
+        """After the forward is enqueued: all-gather [num_visible | viewmat[3].xyz bits] of every view and start
+        the copy of the result to the host (SURVEY 2b-1 for the camera term)."""
+        meta = torch.cat([aux.num_visible.reshape(-1)[:1].to(torch.int32), aux.uniforms_buffer[12:15].to(torch.int32)])
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.metas.view(-1), meta, group=self.group)
+        else:
+            self.metas.view(-1).copy_(meta)
+        self._counts_host = None
+        if self.device.type == "cuda":
+            if self._host is None:
+                self._host = torch.empty(self.world, dtype=torch.int32, pin_memory=True)
+            self._host.copy_(self.metas[:, 0], non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
 
-def allreduce_param_grads_compact(block: torch.Tensor, aux: RenderAux, means: torch.Tensor, n: int, ncoef: int,
-                                  group: Optional[dist.ProcessGroup] = None, pack=None, expand=None) -> torch.Tensor:
-    """Same result as allreduce_param_grads (sum over views, on every rank) through an all-gather of
-    compact per-view records.  One 16-byte all-gather carries the per-view counts that size the padded
-    record exchange.  On the GPU the exchange is enqueued optimistically with the previous step's
-    size (+12.5 %) while the counts travel to the host asynchronously; they are checked before the
-    expansion and, should a view have outgrown the hint, pack + all-gather are simply repeated at the
-    right size — the host never leaves the GPU idle waiting for a number."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return block
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    dev = block.device
-    pack = pack or pack_view_records
-    # one small message per rank: [num_visible | viewmat[3].xyz bits] (SURVEY §2b-1 for the camera term)
-    meta = torch.cat([aux.num_visible.reshape(-1)[:1].to(torch.int32), aux.uniforms_buffer[12:15].to(torch.int32)])
-    metas = torch.empty((world, 4), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(metas.view(-1), meta, group=group)
-    counts = metas[:, 0].contiguous()
-    cams = metas[:, 1:4].contiguous().view(torch.float32)
+    def counts(self):
+        """Per-view visible counts on the host (waits for the copy `begin` started; normally long finished)."""
+        if self._counts_host is None:
+            if self.device.type == "cuda":
+                self._event.synchronize()
+                self._counts_host = [int(x) for x in self._host.tolist()]
+            else:
+                self._counts_host = [int(x) for x in self.metas[:, 0].tolist()]
+        return self._counts_host
 
-    # From 4 views on, the records travel in two halves: the expansion of the first half (float atomics,
-    # L2-bound) overlaps the all-gather of the second (xGMI-bound).
-    chunks = int(os.environ.get("BRUSH_EXCHANGE_CHUNKS", "2" if world >= 4 else "1"))
+    def _ensure_capacity(self, rows: int):
+        if rows <= self.capacity:
+            return
+        self.capacity = _padded_rows(rows + rows // 4)  # 25 % headroom: growth does not re-run the backward every step
+        self.local = torch.empty((self.capacity, _REC), dtype=torch.float32, device=self.device)
+        self.gathered = torch.empty(self.world * self.capacity * _REC, dtype=torch.float32, device=self.device)
 
-    def exchange(rows):
-        rec = pack(block, aux, n, ncoef, rows)
-        per = rows // chunks
-        outs, works = [], []
-        for k in range(chunks):
-            out = torch.empty((world, per, _REC), dtype=torch.float32, device=dev)
-            part = rec[k * per:(k + 1) * per].reshape(-1)
-            works.append(dist.all_gather_into_tensor(out.view(-1), part, group=group, async_op=chunks > 1))
-            outs.append(out)
-        return outs, works, per
+    # -- this view's records -----------------------------------------------------------------
+    def backward_records(self, u, aux: RenderAux, means, log_scales, quats, raw_opacity, out_img, v_out):
+        """brush_render_backward_records into the local buffer.  The first call (no capacity yet) waits for the
+        counts; later calls enqueue at once with the current capacity and `gather` re-runs the (rare) view that
+        outgrew it."""
+        import ctypes as C
 
-    key = (id(group), world, n, ncoef, str(dev))
-    hint = _ROWS_HINT.get(key)
-    got = None
-    if block.is_cuda and hint is not None:
-        host = torch.empty(world, dtype=torch.int32, pin_memory=True)
-        host.copy_(counts, non_blocking=True)
-        seen = torch.cuda.Event()
-        seen.record()
-        got, rows = exchange(hint), hint  # enqueued while the counts are still on their way
-        seen.synchronize()
-        max_count = int(host.max())
-        if max_count > rows:  # a view outgrew the hint: redo at the right size (same decision on every rank)
-            if chunks > 1:
-                for wk in got[1]:
-                    wk.wait()
-            got = None
-    else:
-        max_count = int(counts.max().item())
-    if got is None:
-        rows = _padded_rows(max_count, chunks)
-        got = exchange(rows)
-    _ROWS_HINT[key] = _padded_rows(max_count + max_count // 8, chunks)
-    outs, works, per = got
-    expand = expand or expand_view_records
-    for k in range(chunks):
-        if chunks > 1:
-            works[k].wait()  # the current stream waits for this half only
-        part_rows = counts if chunks == 1 else (counts - k * per).clamp(0, per)
-        expand(outs[k], part_rows, cams, means, block, n, ncoef, rank)
-    return block
+        from . import _lib
+
+        assert means.is_cuda, "brush_amd has no CPU path: tensors must live on the GPU"
+        if self.capacity == 0:
+            self._ensure_capacity(max(self.counts()))
+        self._bwd_args = (u, aux, means, log_scales, quats, raw_opacity, out_img, v_out)
+        l = _lib.lib()
+        n = means.shape[0]
+        w, h = int(u.img_size[0]), int(u.img_size[1])
+        nbytes = C.c_size_t()
+        _lib.check(l.brush_bwd_workspace_size(n, w, h, int(u.sh_degree), C.byref(nbytes)), "brush_bwd_workspace_size")
+        if getattr(self, "_ws", None) is None or self._ws.numel() < nbytes.value:
+            self._ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=self.device)
+        s = aux._as_struct()
+        with torch.cuda.device(self.device):
+            _lib.check(l.brush_render_backward_records(C.byref(u), C.byref(s), means.data_ptr(), log_scales.data_ptr(),
+                                                       quats.data_ptr(), raw_opacity.data_ptr(), n, out_img.data_ptr(),
+                                                       v_out.contiguous().data_ptr(), self.local.data_ptr(), self.capacity,
+                                                       self._ws.data_ptr(), nbytes.value,
+                                                       torch.cuda.current_stream().cuda_stream),
+                       "brush_render_backward_records")
+
+    def set_local_records(self, rec: torch.Tensor):
+        """Test hook (CPU / torch restatement): use `rec` [rows,16] as this view's records."""
+        self._ensure_capacity(rec.shape[0])
+        self.local[:rec.shape[0]].copy_(rec)
+
+    # -- exchange ------------------------------------------------------------------------------
+    def gather(self) -> torch.Tensor:
+        """All-gather of exactly padded(max count) rows per view.  Returns the [W, rows, 16] records."""
+        counts = self.counts()
+        need = max(counts) if counts else 0
+        if need > self.capacity:  # a view grew by more than the headroom since the buffer was sized: redo its records
+            self.regrown += 1
+            self._ensure_capacity(need)
+            if getattr(self, "_bwd_args", None) is not None:
+                self.backward_records(*self._bwd_args)
+        rows = min(_padded_rows(need), self.capacity)
+        self._rows = rows
+        out = self.gathered[:self.world * rows * _REC]
+        part = self.local[:rows].reshape(-1)
+        if self.world > 1:
+            dist.all_gather_into_tensor(out, part, group=self.group)
+        else:
+            out.copy_(part)
+        return out.view(self.world, rows, _REC)
+
+    def _reduce_common(self):
+        import ctypes as C
+
+        from . import _lib
+
+        nbytes = C.c_size_t()
+        _lib.check(_lib.lib().brush_view_index_size(self.n, self.world, C.byref(nbytes)), "brush_view_index_size")
+        if self.index is None or self.index.numel() < nbytes.value:
+            self.index = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        recs = self.gathered[:self.world * self._rows * _REC]
+        view_rows = self.metas[:, 0].contiguous()
+        campos = self.metas[:, 1:4].contiguous().view(torch.float32)
+        return recs, view_rows, campos, nbytes.value
+
+    def reduce_dense(self, means: torch.Tensor, block: Optional[torch.Tensor] = None):
+        """Sum over views into the dense gradient block (brush_reduce_view_records).  Returns (grads, block);
+        v_xy of the block is left untouched (per-view statistic)."""
+        from . import _lib
+
+        n, ncoef = self.n, self.ncoef
+        layout, total = grad_block_layout(n, ncoef)
+        if block is None:
+            block = torch.empty(max(total, 1), dtype=torch.float32, device=self.device)
+        recs, view_rows, campos, ibytes = self._reduce_common()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().brush_reduce_view_records(
+                recs.data_ptr(), self.world, self._rows, view_rows.data_ptr(), campos.data_ptr(), means.data_ptr(), n,
+                self.degree, _seg_ptr(block, layout, "v_means"), _seg_ptr(block, layout, "v_scales"),
+                _seg_ptr(block, layout, "v_quats"), _seg_ptr(block, layout, "v_sh"), _seg_ptr(block, layout, "v_opac"),
+                self.index.data_ptr(), ibytes, torch.cuda.current_stream().cuda_stream), "brush_reduce_view_records")
+        self._keep = (view_rows, campos)  # alive until the kernel has run
+
+        def seg(name, shape):
+            off, sz = layout[name]
+            return block[off:off + sz].view(shape)
+
+        grads = {"v_means": seg("v_means", (n, 3)), "v_scales": seg("v_scales", (n, 3)), "v_quats": seg("v_quats", (n, 4)),
+                 "v_opac": seg("v_opac", (n,)), "v_sh": seg("v_sh", (n, ncoef, 3))}
+        return grads, block
+
+    def reduce_adam(self, cfg, img_size, means, log_scales, rotation, raw_opacity, sh, moment1, moment2,
+                    next_quats_fed=None, grad_2d_accum=None, xy_grad_counts=None):
+        """Sum over views straight into the Adam update of every parameter (brush_reduce_view_records_adam)."""
+        import ctypes as C
+
+        from . import _lib
+
+        recs, view_rows, campos, ibytes = self._reduce_common()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().brush_reduce_view_records_adam(
+                recs.data_ptr(), self.world, self._rows, view_rows.data_ptr(), campos.data_ptr(), C.byref(cfg),
+                int(img_size[0]), int(img_size[1]), means.data_ptr(), log_scales.data_ptr(), rotation.data_ptr(),
+                raw_opacity.data_ptr(), sh.data_ptr(), self.n, self.degree, moment1.data_ptr(), moment2.data_ptr(),
+                ptr(next_quats_fed), ptr(grad_2d_accum), ptr(xy_grad_counts), self.index.data_ptr(), ibytes,
+                torch.cuda.current_stream().cuda_stream), "brush_reduce_view_records_adam")
+        self._keep = (view_rows, campos)
 
 
 def densification_stats(v_xy: torch.Tensor, aux: RenderAux, img_size) -> torch.Tensor:

@@ -198,11 +198,13 @@ class SplatTrainer:
         return c.lr_mean * gamma ** self.iter * scene_extent
 
     def step(self, splats: Splats, camera: Camera, gt_image: torch.Tensor, scene_extent: float = 1.0,
-             batch_views: int = 1, grad_sync: Optional[Callable] = None):
+             batch_views: int = 1, grad_sync: Optional[Callable] = None, exchange=None):
         """One reference training iteration on one view (batch size is 1 in the reference,
         train.rs:216-219).  With view-sharded data parallelism call it on each rank with
-        `batch_views` = world size and `grad_sync(block, aux)` summing the gradient block over views
-        (brush_amd.dist.allreduce_param_grads[_compact])."""
+        `batch_views` = world size and either `exchange` = a brush_amd.dist.ViewExchange (per-view gradient
+        records all-gathered, summed per splat in view order and fed straight into Adam: every rank applies
+        the same bits) or `grad_sync(block, aux)` summing the dense gradient block over views
+        (brush_amd.dist.allreduce_param_grads)."""
         c = self.config
         h, w = int(gt_image.shape[0]), int(gt_image.shape[1])
         n, ncoef = splats.num_splats(), int(splats.sh_coeffs.shape[1])
@@ -225,6 +227,8 @@ class SplatTrainer:
                 _lib.check(l.brush_normalize_quats(quats.data_ptr(), norm_rot.data_ptr(), n, stream), "brush_normalize_quats")
         self.invalidate_cached_rotation()
         pred, aux, u = R._forward_impl(camera, (w, h), means, log_scales, norm_rot, sh, raw_opac, False, None)
+        if exchange is not None:
+            exchange.begin(aux)  # the per-view counts start travelling while the loss and the backward run
         loss, v_pred = l1_ssim_loss(pred, gt_image, c.ssim_weight, c.ssim_window_size, 1.0 / batch_views)
         do_refine = self.iter < c.max_refine_step and self.iter >= c.warmup_steps and self.iter % c.refine_every == 1
         pre_step = None
@@ -235,7 +239,17 @@ class SplatTrainer:
                                    c.lr_coeffs_dc, 1.0 / c.lr_coeffs_sh_scale, 0.9, 0.999, 1e-15, self.opt_time + 1, 1)
         want_stats = self.iter > c.warmup_steps  # housekeeping, train.rs:284-316
         with torch.cuda.device(means.device):
-            if grad_sync is None and self.fused_backward:
+            if exchange is not None:
+                # view-sharded data parallelism: records of this view -> all-gather -> per-splat sum -> Adam
+                exchange.backward_records(u, aux, means, log_scales, norm_rot, raw_opac, pred, v_pred)
+                exchange.gather()
+                next_rot = torch.empty_like(quats)
+                exchange.reduce_adam(cfg, (w, h), means, log_scales, quats, raw_opac, sh, self.moment1, self.moment2,
+                                     next_rot, self.grad_2d_accum if want_stats else None,
+                                     self.xy_grad_counts if want_stats else None)
+                self._norm_rot, self._norm_rot_key = next_rot, (quats.data_ptr(), n, splats.rotation._version)
+                self._norm_rot_owner = splats.rotation
+            elif grad_sync is None and self.fused_backward:
                 # single view: gradients go straight through the optimizer inside the backward kernel
                 nbytes = C.c_size_t()
                 _lib.check(l.brush_bwd_workspace_size(n, w, h, int(u.sh_degree), C.byref(nbytes)), "brush_bwd_workspace_size")

@@ -151,28 +151,36 @@ int brush_render_backward(const BrushUniforms *h_uniforms, const BrushAux *h_aux
                           float *v_quats, float *v_sh, float *v_opac, void *workspace,
                           size_t workspace_bytes, brush_stream_t stream);
 
-/* ---- multi-GPU gradient exchange (build extension; the reference is single-device) ------- */
-/* Record layout (16 f32 = 64 bytes per visible splat of one view):
- *   [gid as u32 bits | v_means(3) | v_scales(3) | v_quats(4) | v_opac | v_sh[gid,0,:](3) | 1.0]
- * brush_pack_view_records writes rows c < min(num_visible, max_rows) of `records` (compact = depth
- * order) from the dense gradients of brush_render_backward; rows beyond are left untouched. */
-int brush_pack_view_records(const BrushAux *h_aux, uint32_t n, uint32_t sh_degree, const float *v_means,
-                            const float *v_scales, const float *v_quats, const float *v_opac,
-                            const float *v_sh, float *records, uint32_t max_rows, brush_stream_t stream);
-/* Sums the records of W views into the dense parameter-gradient arrays.  records:
- * [W * rows_per_view][16]; view v owns rows [v*rows_per_view, v*rows_per_view + view_rows[v])
- * (view_rows: device array [W]); campos: [W][3] = viewmat[3].xyz of each view (the term the
- * reference uses as camera position, project_visible.wgsl:232-233); means: [N,3].  The SH rows are
- * rebuilt as Y(normalize(mean - campos)) (x) v_sh0 / Y0 (gather_grads.wgsl:186-222).
- * skip_view = 0xFFFFFFFF: the arrays are zero-filled first and all W views are added;
- * skip_view = r: the arrays are expected to hold view r's dense gradients already (the caller's
- * own backward output) and the other W-1 views are added on top.  brush_amd/dist.py shows the
- * RCCL all-gather that produces `records`. */
-int brush_expand_view_records(const float *records, uint32_t num_records, uint32_t rows_per_view,
-                              const uint32_t *view_rows, const float *campos, const float *means,
-                              uint32_t n, uint32_t sh_degree, uint32_t skip_view, float *v_means,
-                              float *v_scales, float *v_quats, float *v_opac, float *v_sh,
-                              brush_stream_t stream);
+/* ---- view-sharded data parallelism (build extension; the reference is single-device, batch 1:
+ *      crates/brush-train/src/train.rs:216-219) ------------------------------------------------ */
+/* One process per GPU renders one view of the replicated splats; the step needs the SUM over views of the
+ * parameter gradients.  A view's gradient is non-zero only for its visible splats and its SH row is rank one
+ * (v_sh[g] = Y(dir_view(g)) (x) v_rgb[g], gather_grads.wgsl:186-222), so it is exchanged as one 64-byte record
+ * per VISIBLE splat (16 f32, compact = depth order):
+ *   [gid as u32 bits | v_means(3) | v_scales(3) | v_quats(4) | v_opac | v_rgb(3) | |v_xy * (w/2, h/2)|]
+ * instead of 52+12C bytes per splat.  The caller all-gathers the records (RCCL; brush_amd/dist.py), then the
+ * per-splat sum over views runs in view order 0..W-1 without atomics: bit-identical on every rank and from run
+ * to run, so replicated parameters stay replicated.
+ *
+ * brush_render_backward_records: brush_render_backward without the dense outputs.  Writes rows
+ * c < min(num_visible, max_rows) of `records` ([max_rows][16], 16-byte aligned); rows beyond max_rows are DROPPED:
+ * size max_rows from the view's num_visible (known after the forward).  Same workspace as brush_render_backward. */
+int brush_render_backward_records(const BrushUniforms *h_uniforms, const BrushAux *h_aux, const float *means,
+                                  const float *log_scales, const float *quats, const float *raw_opacity, uint32_t n,
+                                  const float *out_img, const float *v_out, float *records, uint32_t max_rows,
+                                  void *workspace, size_t workspace_bytes, brush_stream_t stream);
+/* Scratch of the reduction: num_views * n u32 (row of splat g in view v's records).  It needs no initialisation
+ * and no reset between steps: entries are validated against the record they point to. */
+int brush_view_index_size(uint32_t n, uint32_t num_views, size_t *bytes);
+/* Sum over views -> dense gradients.  records: [num_views][rows_per_view][16]; view v owns its first
+ * view_rows[v] rows (device array [num_views], values > rows_per_view are clamped); campos: [num_views][3] =
+ * viewmat[3].xyz of each view (the term the reference uses as camera position, project_visible.wgsl:232-233);
+ * means: [N,3].  Every element of v_means [N,3] v_scales [N,3] v_quats [N,4] v_sh [N,C,3] v_opac [N] is written
+ * (0 for splats no view sees). */
+int brush_reduce_view_records(const float *records, uint32_t num_views, uint32_t rows_per_view,
+                              const uint32_t *view_rows, const float *campos, const float *means, uint32_t n,
+                              uint32_t sh_degree, float *v_means, float *v_scales, float *v_quats, float *v_sh,
+                              float *v_opac, void *view_index, size_t view_index_bytes, brush_stream_t stream);
 
 /* ---- training iteration around the op (build extension) -------------------- */
 /* The reference's SplatTrainer::step (crates/brush-train/src/train.rs:211-393) wraps the op in
@@ -225,6 +233,19 @@ int brush_render_backward_adam(const BrushUniforms *uniforms, const BrushAux *au
                                const float *v_out, float *v_xy, float *moment1, float *moment2,
                                float *next_quats_fed, float *grad_2d_accum, float *xy_grad_counts,
                                void *workspace, size_t workspace_bytes, brush_stream_t stream);
+/* brush_reduce_view_records and brush_adam_step in one pass (data-parallel counterpart of
+ * brush_render_backward_adam): the summed gradients go straight through the optimizer update, every rank applies
+ * the same bits.  means / log_scales / rotation / raw_opacity / sh are updated in place (means is also the source
+ * of the SH view directions: each splat is read before it is written).  width / height: image size of the
+ * statistics (train.rs:300-302).  Optional (NULL to skip): next_quats_fed [N,4]; grad_2d_accum / xy_grad_counts
+ * [N] += sum over views of the record's |v_xy * (w/2, h/2)| / number of views that saw the splat
+ * (train.rs:284-316 for a batch of views). */
+int brush_reduce_view_records_adam(const float *records, uint32_t num_views, uint32_t rows_per_view,
+                                   const uint32_t *view_rows, const float *campos, const BrushAdamConfig *cfg,
+                                   uint32_t width, uint32_t height, float *means, float *log_scales, float *rotation,
+                                   float *raw_opacity, float *sh, uint32_t n, uint32_t sh_degree, float *moment1,
+                                   float *moment2, float *next_quats_fed, float *grad_2d_accum, float *xy_grad_counts,
+                                   void *view_index, size_t view_index_bytes, brush_stream_t stream);
 /* normalized[i] = rotation[i] / |rotation[i]| (gaussian_splats.rs:174-175); [N,4], 16-byte aligned. */
 int brush_normalize_quats(const float *rotation, float *normalized, uint32_t n, brush_stream_t stream);
 /* train.rs:284-316: grad_2d_accum[g] += |v_xy[g] * (w/2, h/2)|; xy_grad_counts[g] += 1 for every

@@ -1,9 +1,10 @@
 """N>1 path on CPU with the gloo backend, world_size 2 (no GPU needed).
 
-Each rank plays one GPU: it produces the dense gradient block of ITS view (computed here by the
-CPU oracle, since the HIP op has no CPU path), the block prefix is all-reduced with
-brush_amd.dist, and the result must equal the sum of the two per-view gradients.  Also checks the
-block layout, view sharding and the densification-statistics reduce.
+Each rank plays one GPU: it produces the dense gradients of ITS view (computed here by the CPU oracle, since the
+HIP op has no CPU path).  Both exchange forms of brush_amd.dist run over gloo: the dense all-reduce of the block
+prefix, and the ViewExchange of 64-byte records (sizing, exact-size all-gather, per-splat sum in view order through
+the torch restatements of the HIP kernels) which must give the same sum AND the same bits on both ranks.  Also
+checks the block layout, view sharding and the densification statistics.
 """
 import os
 import socket
@@ -80,18 +81,23 @@ def _worker(rank, world, port, n, w, h, deg, q):
                         tile_bins=as_i32(aux_np["tile_bins"]), compact_gid_from_isect=as_i32(aux_np["compact_gid_from_isect"]),
                         global_from_compact_gid=as_i32(aux_np["global_from_compact_gid"]),
                         compact_from_global_gid=_inverse_map(aux_np, n), overflow=torch.zeros(1, dtype=torch.int32))
-        # compact exchange: all-gather of 60-byte records of the visible splats + local expansion
+        # record exchange: all-gather of 64-byte records of the visible splats + per-splat sum in view order
         ub = torch.zeros(28, dtype=torch.int32)
         ub[:16] = torch.from_numpy(_view_uniforms(rank, w, h, deg)["viewmat"].view(np.int32).copy())
         aux.uniforms_buffer = ub
-        block_c = torch.from_numpy(block_np.copy())
-        BD.allreduce_param_grads_compact(block_c, aux, torch.from_numpy(cloud["means"]), n, ncoef,
-                                         pack=BD.pack_view_records_torch, expand=BD.expand_view_records_torch)
+        xchg = BD.ViewExchange(n, ncoef, torch.device("cpu"))
+        xchg.begin(aux)
+        rows = -(-max(xchg.counts()) // 256) * 256
+        dense = {k: torch.from_numpy(g[k]) for k in ("v_means", "v_scales", "v_quats", "v_opac", "v_sh", "v_xy")}
+        xchg.set_local_records(BD.records_from_dense_torch(dense, aux, n, (w, h), rows))
+        recs = xchg.gather()
+        red = BD.reduce_view_records_torch(recs, xchg.metas[:, 0], xchg.metas[:, 1:4].contiguous().view(torch.float32),
+                                           torch.from_numpy(cloud["means"]), n, ncoef)
         stats = BD.densification_stats(torch.from_numpy(g["v_xy"]), aux, (w, h))
         local_stats = stats.clone()
         BD.allreduce_densification_stats(stats)
         q.put((rank, block.numpy(), block_np, local_stats.numpy(), stats.numpy(), int(aux_np["num_visible"][0]),
-               block_c.numpy()))
+               {k: v.numpy() for k, v in red.items()}))
     finally:
         dist.destroy_process_group()
 
@@ -126,19 +132,24 @@ def test_view_sharded_allreduce_gloo_world2():
         assert np.array_equal(reduced[prefix:], local[prefix:]), "v_xy (per-view statistic) must not be reduced"
         # the two views differ, so the reduce really changed something
         assert not np.array_equal(reduced[:prefix], local[:prefix])
-    # the compact exchange gives the same dense sum (f32 summation order / one extra rounding aside)
+    # the record exchange gives the same dense sum (one extra rounding in v_rgb = v_sh0 / Y0 aside) ...
     layout, _ = grad_block_layout(n, ncoef)
     for r in range(world):
-        compact = res[r][5]
+        red = res[r][5]
         for name in ("v_means", "v_scales", "v_quats", "v_opac", "v_sh"):
             off, sz = layout[name]
-            a, b = compact[off:off + sz].astype(np.float64), want[off:off + sz].astype(np.float64)
+            a, b = red[name].reshape(-1).astype(np.float64), want[off:off + sz].astype(np.float64)
             scale = np.abs(b).max() + 1e-30
             assert np.abs(a - b).max() <= 2e-6 * scale, (name, np.abs(a - b).max(), scale)
-        assert np.array_equal(compact[prefix:], res[r][1][prefix:])
+    # ... and the SAME BITS on every rank (replicated parameters must stay replicated), statistics included
+    for name in res[0][5]:
+        assert np.array_equal(res[0][5][name].view(np.uint32), res[1][5][name].view(np.uint32)), name
     # densification stats: sums over views; visibility row counts views in which a splat is visible
     s_sum = res[0][2] + res[1][2]
     assert np.allclose(res[0][3], s_sum) and np.allclose(res[1][3], s_sum)
+    # the records carry the same statistics (|v_xy * (w/2, h/2)| per view, views that saw the splat)
+    assert np.allclose(res[0][5]["xy_norm"], s_sum[0], rtol=1e-6, atol=1e-12)
+    assert np.array_equal(res[0][5]["views_seen"], s_sum[1])
     for r in range(world):
         assert int(res[r][2][1].sum()) == res[r][4]  # row 1 of the local stats marks exactly V splats
     assert BD.shard_views(8, 1, 2) == [1, 3, 5, 7] and BD.shard_views(3, 2, 4) == [2]

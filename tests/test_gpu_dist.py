@@ -1,8 +1,9 @@
-"""GPU check of the compact gradient exchange end to end: two ranks share the one GPU of the test box
-and talk over gloo (RCCL refuses two ranks on one device); every rank runs the HIP op on its own view,
-packs, all-gathers and expands with the HIP kernels, and the result is compared with the dense sum of
-the two views' gradient blocks.  The second and third exchange go through the optimistic sizing path
-(previous size + 12.5 %): once with a view that outgrew the hint (redo), once within it."""
+"""GPU check of the view-sharded gradient exchange end to end: two ranks share the one GPU of the test box and talk
+over gloo (RCCL refuses two ranks on one device).  Every rank runs the HIP op on its own view, writes its 64-byte
+records (brush_render_backward_records), all-gathers them and reduces them with the HIP kernel; the result is compared
+with the dense sum of the two views' gradient blocks, must be BIT-IDENTICAL on the two ranks, and the fused
+sum-into-Adam form must leave the same parameters on both ranks.  The camera backs off between steps so that a view
+outgrows the records buffer after its backward was enqueued (the re-run path)."""
 import os
 import socket
 
@@ -25,67 +26,117 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, chunks):
-    os.environ["BRUSH_EXCHANGE_CHUNKS"] = str(chunks)
+def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        import ctypes as C
+
         import brush_amd
+        from brush_amd import _lib
         from brush_amd import dist as BD
         from brush_amd import render as R
 
         dev = torch.device("cuda:0")
         n, w, h, deg = 40000, 320, 200, 2
-        C = (deg + 1) ** 2
+        ncoef = (deg + 1) ** 2
         cloud = H.synthetic_cloud(n, deg, seed=17, mean_mult=0.003)
         p = {k: torch.from_numpy(v).to(dev) for k, v in cloud.items()}
         c = H.reference_test_camera(w, h)
+        xchg = BD.ViewExchange(n, ncoef, dev)
         results = []
-        # step 0: narrow views; step 1: the camera backs off (more splats visible than hint allows); step 2: same
+        # step 0: narrow views; step 1: the camera backs off (far more splats visible than the buffer holds); step 2: same
         for step, z in enumerate((-6.0, -30.0, -30.0)):
             cam = brush_amd.Camera([0.5 * rank, -0.3 * rank, z], c["rotation_xyzw"], c["fov_x"], c["fov_y"], c["center_uv"])
             out, aux, u = R._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"],
                                           False, 4_000_000)
+            xchg.begin(aux)
             torch.manual_seed(100 + step)
             v_out = torch.randn((h, w, 4), device=dev) / (h * w)
-            g, block = R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], C, out, v_out)
-            pf = BD.param_grad_floats(n, C)
+            # reference: dense gradients of this view, summed over the two views on the CPU
+            g, block = R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], ncoef, out, v_out)
+            pf = BD.param_grad_floats(n, ncoef)
             dense = block[:pf].detach().cpu().clone()
-            dist.all_reduce(dense)                         # reference: dense sum over the two views (CPU gloo)
-            hint_before = dict(BD._ROWS_HINT)
-            BD.allreduce_param_grads_compact(block, aux, p["means"], n, C)
-            got = block[:pf].detach().cpu()
-            err = float((got.double() - dense.double()).abs().max())
-            results.append((step, aux.read_num_visible(), err, float(dense.abs().max()), bool(hint_before)))
-        q.put((rank, results))
+            dist.all_reduce(dense)
+            xchg.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, v_out)
+            recs = xchg.gather()
+            grads, red = xchg.reduce_dense(p["means"])
+            torch.cuda.synchronize()
+            got = red[:pf].detach().cpu()
+            # the HIP record kernel against the torch restatement fed with the HIP dense gradients
+            want_rec = BD.records_from_dense_torch(g, aux, n, (w, h), recs.shape[1])
+            V = aux.read_num_visible()
+            rec_err = float((recs[rank, :V, 1:].double() - want_rec[:V, 1:].double()).abs().max()
+                            / (want_rec[:V, 1:].abs().max() + 1e-30))
+            gid_ok = bool(torch.equal(recs[rank, :V, 0].contiguous().view(torch.int32),
+                                      want_rec[:V, 0].contiguous().view(torch.int32)))
+            results.append(dict(step=step, V=V, err=float((got.double() - dense.double()).abs().max()),
+                                scale=float(dense.abs().max()), rec_err=rec_err, gid_ok=gid_ok,
+                                regrown=xchg.regrown, rows=int(recs.shape[1]), red=got.numpy()))
+        # fused form: the same records straight into Adam == brush_adam_step on the reduced dense gradients
+        params = {k: p[k].clone() for k in ("means", "log_scales", "quats", "raw_opac", "sh")}
+        m1 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
+        m2 = torch.zeros_like(m1)
+        cfg = _lib.BrushAdamConfig(1.6e-4, 0.01, 0.002, 0.05, 0.004, 1.0 / 20.0, 0.9, 0.999, 1e-15, 1, 1)
+        ref = {k: v.clone() for k, v in params.items()}
+        rm1, rm2 = torch.zeros_like(m1), torch.zeros_like(m2)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().brush_adam_step(C.byref(cfg), n, deg, ref["means"].data_ptr(), ref["log_scales"].data_ptr(),
+                                                  ref["quats"].data_ptr(), ref["raw_opac"].data_ptr(), ref["sh"].data_ptr(),
+                                                  grads["v_means"].data_ptr(), grads["v_scales"].data_ptr(),
+                                                  grads["v_quats"].data_ptr(), grads["v_opac"].data_ptr(),
+                                                  grads["v_sh"].data_ptr(), rm1.data_ptr(), rm2.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), "brush_adam_step")
+        acc, cnt = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        xchg.reduce_adam(cfg, (w, h), params["means"], params["log_scales"], params["quats"], params["raw_opac"],
+                         params["sh"], m1, m2, None, acc, cnt)
+        torch.cuda.synchronize()
+        adam = {k: float((params[k].double() - ref[k].double()).abs().max()) for k in params}
+        moved = {k: float((params[k].double() - p[k].double()).abs().max()) for k in params}
+        q.put((rank, results, adam, moved, {k: v.cpu().numpy() for k, v in params.items()},
+               acc.cpu().numpy(), cnt.cpu().numpy()))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("chunks", [1, 2])  # 2 = the overlapped two-half exchange used from 4 views on
-def test_compact_exchange_two_ranks_one_gpu(chunks):
+def test_record_exchange_two_ranks_one_gpu():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, chunks)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
     for _ in range(world):
-        rank, res = q.get(timeout=500)
-        got[rank] = res
+        item = q.get(timeout=500)
+        got[item[0]] = item[1:]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank in range(world):
-        steps = got[rank]
-        assert [s[0] for s in steps] == [0, 1, 2]
-        assert not steps[0][4] and steps[1][4] and steps[2][4]      # hint used from the second exchange on
-        assert steps[1][1] > 1.3 * steps[0][1]                      # step 1 really outgrew the hint
-        for step, V, err, scale, _ in steps:
-            assert V > 1000
-            assert err <= 2e-6 * scale, (rank, step, err, scale)
+        steps = got[rank][0]
+        assert [s["step"] for s in steps] == [0, 1, 2]
+        assert steps[1]["V"] > 1.3 * steps[0]["V"]                 # step 1 really outgrew the buffer ...
+        assert steps[1]["regrown"] >= 1 and steps[2]["regrown"] == steps[1]["regrown"]  # ... once
+        for s in steps:
+            assert s["V"] > 1000 and s["gid_ok"]
+            assert s["rec_err"] <= 2e-6                            # one extra rounding in v_rgb = v_sh0 / Y0
+            assert s["err"] <= 2e-6 * s["scale"], (rank, s["step"], s["err"], s["scale"])
+    # the reduced gradients are the same bits on both ranks, every step
+    for a, b in zip(got[0][0], got[1][0]):
+        assert np.array_equal(a["red"].view(np.uint32), b["red"].view(np.uint32)), a["step"]
+    # fused Adam: equal to brush_adam_step on the reduced gradients (same formulas, other kernel), really moved the
+    # parameters, and left the same bits on both ranks; statistics = two views' worth
+    for rank in range(world):
+        adam, moved = got[rank][1], got[rank][2]
+        for k in adam:
+            # (an ulp of the parameter itself: the two kernels round the quaternion chain rule differently)
+            assert moved[k] > 0 and adam[k] <= 1e-5 * moved[k] + 1e-8, (k, adam[k], moved[k])
+    for k in got[0][3]:
+        assert np.array_equal(got[0][3][k].view(np.uint32), got[1][3][k].view(np.uint32)), k
+    assert np.array_equal(got[0][4], got[1][4]) and np.array_equal(got[0][5], got[1][5])
+    assert got[0][5].max() == 2.0 and got[0][4].max() > 0
