@@ -135,7 +135,7 @@ def test_record_exchange_two_ranks_one_gpu():
         adam, moved = got[rank][1], got[rank][2]
         for k in adam:
             # (an ulp of the parameter itself: the two kernels round the quaternion chain rule differently)
-            assert moved[k] > 0 and adam[k] <= 1e-5 * moved[k] + 1e-8, (k, adam[k], moved[k])
+            assert moved[k] > 0 and adam[k] <= 1e-5 * moved[k] + 2.5e-7, (k, adam[k], moved[k])
     for k in got[0][3]:
         assert np.array_equal(got[0][3][k].view(np.uint32), got[1][3][k].view(np.uint32)), k
     assert np.array_equal(got[0][4], got[1][4]) and np.array_equal(got[0][5], got[1][5])

@@ -691,10 +691,9 @@ def test_view_records_round_trip(dev):
     vis[aux.global_from_compact_gid[:V].long()] = True
     assert not bool(grads["v_sh"][~vis].any()) and not bool(grads["v_means"][~vis].any())
     # a stale index (left by this call) must not leak into a later reduction of other records
-    recs2 = recs.clone()
-    xchg.gathered[:recs2.numel()].view_as(recs2)[0, :V // 2, 0] = torch.tensor(n + 5, dtype=torch.int32, device=dev).view(torch.float32)
+    dropped = recs[0, :V // 2, 0].contiguous().view(torch.int32).long().clone()  # `recs` is a view of xchg.gathered
+    recs[0, :V // 2, 0] = torch.tensor(n + 5, dtype=torch.int32, device=dev).view(torch.float32)
     grads2, _ = xchg.reduce_dense(p["means"])
-    dropped = recs[0, :V // 2, 0].contiguous().view(torch.int32).long()
     assert not bool(grads2["v_means"][dropped].any())  # records whose gid is out of range are ignored, entries re-validated
 
 
