@@ -4,56 +4,59 @@
 // pass, 5 launches per pass (count / reduce / scan / scan_add / scatter), element count read
 // from a GPU buffer, only the low `sorting_bits` sorted.  32-bit keys = 40 launches.
 //
-// gfx950 design: 8-bit digits (half the passes), 3 launches per pass, wave64 ranking.
-//   k_upsweep   : 256-thread block per tile; per-wave LDS histograms -> counts[digit][tile]
-//   k_scan      : one block per digit scans counts[digit][*] over tiles in place, writes totals[]
-//   k_downsweep : re-reads the tile (coalesced); each wave ranks its contiguous chunk with ballot
-//                 match-any masks (8 x v_cmp per key on 64-bit masks), the lowest peer lane bumps
-//                 the wave's private LDS counter; 4-wave combine; the 256 digit bases come from a
-//                 block scan of totals[]; scatter.
-// The element count stays on the device (*d_n): grids are sized for max_n and surplus blocks exit
-// on their first instruction.  The tile size is also chosen ON THE DEVICE from *d_n (1, 2, 4, 8 or
-// 16 keys per lane, the smallest that keeps the tile count <= 256 — measured optimum of 64..2048): a 100 k-key sort then spreads
-// over ~200 workgroups instead of 25, and an 8 M-key sort still uses 4096-key tiles.  All three
-// kernels derive the same value, so the partition is consistent.
-// Stability: tiles, wave chunks, rounds and lanes are all ranked in index order.
-// Traffic per pass: 4 B/key (upsweep) + 16 B/pair (downsweep).  Roofline: HBM at large n, launch
-// latency at n ~ 100 k.  The pass structure sorts exactly the reference's 4*ceil(bits/4) low bits.
+// gfx950 design: 8-bit digits (half the passes), 1024-thread workgroups (16 waves), tiles of
+// 1024 x {1,2,4,8,16} keys chosen ON THE DEVICE from *d_n: at most 128 tiles while that fits (a 103 k-key
+// sort: 101 tiles of 1024 keys, a 419 k-key sort: 103 of 4096), 16384-key tiles when the sort is large.
+//   k_upsweep   : per-wave LDS histograms -> counts of the tile's 256 digits
+//   k_scan      : (large sorts only) one block per digit scans counts[digit][*] over the tiles
+//   k_downsweep : every wave ranks its contiguous chunk with ballot match-any masks (8 x v_cmp per
+//                 key on 64-bit masks, the lowest peer lane bumps the wave's private LDS counter),
+//                 16-wave combine, then the pairs are REORDERED BY DIGIT IN LDS and written out so
+//                 that consecutive lanes write consecutive addresses of a digit run (round 1 scattered
+//                 one dword per lane into 256 runs: 2.1x write amplification at the HBM counters).
+// Two launch shapes, chosen on the host from max_n:
+//   * FUSED (max_n <= 512 tiles of 16384 keys, i.e. the reference's 8.39 M intersection cap and below):
+//     2 launches per pass.  counts are laid out [tile][digit]; every downsweep block sums the rows of the
+//     tiles before it and of all tiles itself (T coalesced 1-KiB row reads, T = the ACTUAL tile count of
+//     *d_n, ~26-64 at the headline scene) instead of waiting for a scan launch: at 100 k - 400 k keys a
+//     pass is bound by kernel boundaries (~4 us each), not by bytes.
+//   * otherwise 3 launches per pass with counts laid out [digit][tile] and the scan kernel.
+// The element count stays on the device (*d_n): grids are sized for max_n and surplus blocks exit on
+// their first instruction.  Stability: tiles, wave chunks, rounds and lanes are all ranked in index order.
+// Traffic per pass: 4 B/key (upsweep) + 16 B/pair (downsweep).  Roofline: HBM at large n, kernel
+// boundaries at n ~ 100 k.  The pass structure sorts exactly the reference's 4*ceil(bits/4) low bits.
 #include "common.hpp"
 
 namespace brush {
 namespace {
 
-constexpr uint32_t kSortThreads = 256;
-constexpr uint32_t kSortWaves = kSortThreads / kWave;
+constexpr uint32_t kSortThreads = 1024;
+constexpr uint32_t kSortWaves = kSortThreads / kWave;  // 16
 constexpr uint32_t kSortMaxItems = 16;
-constexpr uint32_t kSortTargetTiles = 256;
+// Measured at the headline scene (sweep of the keys per lane): the 103 k-key depth sort is fastest with 1 key per
+// lane (101 tiles), the 419 k-key tile sort with 4 (103 tiles): ~100 workgroups either way.
+constexpr uint32_t kSortTargetTiles = 128;
 constexpr uint32_t kRadix = 256;
+constexpr uint32_t kMaxTileKeys = kSortThreads * kSortMaxItems;  // 16384
+constexpr uint32_t kFusedMaxTiles = 512;
 
-// Keys per lane for a sort of n keys: smallest power of two K in [1,16] with n/(256 K) <= 256.
+// Keys per lane for a sort of n keys: smallest power of two K in [1,16] with n / (1024 K) <= 128.
 __host__ __device__ __forceinline__ uint32_t sort_items(uint32_t n) {
     uint32_t k = 1;
     while (k < kSortMaxItems && (uint64_t)kSortThreads * k * kSortTargetTiles < n) k <<= 1;
     return k;
 }
-// Upper bound of the tile count over every n <= max_n (size of one row of the counts table).
+// Upper bound of the tile count over every n <= max_n.
 inline uint32_t sort_max_tiles(uint32_t max_n) {
-    uint32_t best = 1;
-    for (uint32_t k = 1; k <= kSortMaxItems; k <<= 1) {
-        // largest n that still selects k
-        uint64_t hi = (k == kSortMaxItems) ? max_n : (uint64_t)kSortThreads * k * kSortTargetTiles;
-        if (hi > max_n) hi = max_n;
-        const uint32_t tiles = (uint32_t)((hi + (uint64_t)kSortThreads * k - 1) / ((uint64_t)kSortThreads * k));
-        if (tiles > best) best = tiles;
-    }
-    return best;
+    const uint32_t big = (uint32_t)(((uint64_t)max_n + kMaxTileKeys - 1) / kMaxTileKeys);
+    return big > kSortTargetTiles ? big : kSortTargetTiles;  // n <= 128 * 1024 * K selects K: never more than 128 tiles
 }
 
+template <bool FUSED>
 __global__ __launch_bounds__(kSortThreads) void k_sort_upsweep(const uint32_t *__restrict__ keys,
-                                                              const uint32_t *__restrict__ d_n,
-                                                              uint32_t max_n, uint32_t shift, uint32_t mask,
-                                                              uint32_t *__restrict__ counts,
-                                                              uint32_t max_tiles) {
+                                                              const uint32_t *__restrict__ d_n, uint32_t max_n,
+                                                              uint32_t shift, uint32_t mask,
+                                                              uint32_t *__restrict__ counts, uint32_t max_tiles) {
     const uint32_t n = min(*d_n, max_n);
     const uint32_t items = sort_items(n);
     const uint32_t tile_keys = kSortThreads * items;
@@ -69,11 +72,17 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_upsweep(const uint32_t *_
         if (idx < n) atomicAdd(&hist[wid][(keys[idx] >> shift) & mask], 1u);
     }
     __syncthreads();
-    const uint32_t d = threadIdx.x;
-    counts[(size_t)d * max_tiles + tile] = hist[0][d] + hist[1][d] + hist[2][d] + hist[3][d];
+    if (threadIdx.x < kRadix) {
+        const uint32_t d = threadIdx.x;
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kSortWaves; w++) c += hist[w][d];
+        if (FUSED) counts[(size_t)tile * kRadix + d] = c;
+        else counts[(size_t)d * max_tiles + tile] = c;
+    }
 }
 
-// Block d: exclusive scan over tiles of counts[d][*]; totals[d] = number of keys with digit d.
+// Large sorts: block d = exclusive scan over tiles of counts[d][*]; totals[d] = number of keys with digit d.
 __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ counts,
                                                    const uint32_t *__restrict__ d_n, uint32_t max_n,
                                                    uint32_t max_tiles, uint32_t *__restrict__ totals) {
@@ -101,43 +110,93 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ counts
     if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
-template <uint32_t ITEMS>
+// LDS of the downsweep: the tile's pairs reordered by digit (128 KiB at 16 keys per lane) + the per-wave
+// digit counters.  One 1024-thread workgroup per CU.
+struct DownLds {
+    uint32_t keys[kMaxTileKeys];
+    uint32_t vals[kMaxTileKeys];
+    uint32_t wave_hist[kSortWaves][kRadix];
+    uint32_t digit_base[kRadix];  // global position of the tile's first key of each digit
+    uint32_t tile_start[kRadix];  // position inside the tile (after the reorder) of each digit's run
+    uint32_t part[4][kRadix];     // FUSED: partial column sums (keys of earlier tiles), 4 tile-quarters
+    uint32_t part_all[4][kRadix]; // FUSED: partial column sums over all tiles
+    uint32_t wave_tot2[4][2];
+};
+
+// Exclusive scans of two 256-entry arrays held by threads 0..255 (one value of each per thread) behind the same
+// two barriers; all 1024 threads must call.
+__device__ __forceinline__ void block_excl_scan256_pair(uint32_t &a, uint32_t &b, uint32_t (*wave_tot)[2]) {
+    const uint32_t ia = wave_inclusive_scan(a), ib = wave_inclusive_scan(b);
+    if (threadIdx.x < kRadix && lane_id() == 63) {
+        wave_tot[threadIdx.x / kWave][0] = ia;
+        wave_tot[threadIdx.x / kWave][1] = ib;
+    }
+    __syncthreads();
+    uint32_t oa = ia - a, ob = ib - b;
+    for (uint32_t w = 0; w < threadIdx.x / kWave && w < 4; w++) {
+        oa += wave_tot[w][0];
+        ob += wave_tot[w][1];
+    }
+    __syncthreads();
+    a = oa, b = ob;
+}
+
+template <bool FUSED, uint32_t ITEMS>
 __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys_in,
                                                const uint32_t *__restrict__ vals_in,
                                                uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                uint32_t n, uint32_t shift, uint32_t mask,
                                                const uint32_t *__restrict__ counts,
                                                const uint32_t *__restrict__ totals, uint32_t max_tiles,
-                                               uint32_t (*wave_hist)[kRadix], uint32_t *digit_base,
-                                               uint32_t *wave_tot) {
+                                               DownLds &L) {
+    constexpr uint32_t kTileKeys = kSortThreads * ITEMS;
+    constexpr bool kReorder = ITEMS > 2;  // small sorts: the scatter is a few hundred KB, not worth two barriers
     const uint32_t tile = blockIdx.x;
     const uint32_t wid = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
-    for (uint32_t i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&wave_hist[0][0])[i] = 0;
-
-    // Global base of digit d for this tile = (#keys with smaller digit) + (same digit, earlier tiles).
-    {
-        const uint32_t d = threadIdx.x;
-        const uint32_t v = totals[d];
-        const uint32_t incl = wave_inclusive_scan(v);
-        if (lane == 63) wave_tot[wid] = incl;
-        __syncthreads();
-        uint32_t off = incl - v;
-        for (uint32_t w = 0; w < wid; w++) off += wave_tot[w];
-        digit_base[d] = off + counts[(size_t)d * max_tiles + tile];
-    }
+    for (uint32_t i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&L.wave_hist[0][0])[i] = 0;
 
     // Each wave owns a contiguous chunk of 64*ITEMS keys; round i covers keys chunk + i*64 + lane.
-    const uint32_t chunk = tile * (kSortThreads * ITEMS) + wid * (kWave * ITEMS);
-    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+    // The loads are issued first so that they are in flight during the table sums below.
+    const uint32_t tile_base = tile * kTileKeys;
+    const uint32_t chunk = tile_base + wid * (kWave * ITEMS);
+    uint32_t key[ITEMS], val[ITEMS];
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; i++) {
         const uint32_t idx = chunk + i * kWave + lane;
         key[i] = idx < n ? keys_in[idx] : 0u;
         val[i] = idx < n ? vals_in[idx] : 0u;
     }
-    __syncthreads();  // wave_hist zeroed
+    // FUSED: counts[t][d]; thread (quarter qt, digit d) sums the rows t = qt, qt+4, ... of the ACTUAL tiles:
+    // keys of digit d in earlier tiles / in all tiles.
+    uint32_t glob_base = 0, glob_tot = 0;
+    if (FUSED) {
+        const uint32_t num_tiles = (n + kTileKeys - 1) / kTileKeys;
+        const uint32_t d = threadIdx.x & (kRadix - 1), qt = threadIdx.x / kRadix;
+        uint32_t below = 0, all = 0;
+        // 8 independent row loads in flight per thread: the loop is latency-, not bandwidth-bound
+        for (uint32_t t0 = qt; t0 < num_tiles; t0 += 32) {
+            uint32_t c[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t t = t0 + 4 * j;
+                c[j] = t < num_tiles ? counts[(size_t)t * kRadix + d] : 0u;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                all += c[j];
+                below += (t0 + 4 * j) < tile ? c[j] : 0u;
+            }
+        }
+        L.part[qt][d] = below;
+        L.part_all[qt][d] = all;
+    } else if (threadIdx.x < kRadix) {
+        glob_tot = totals[threadIdx.x];
+        glob_base = counts[(size_t)threadIdx.x * max_tiles + tile];
+    }
+    __syncthreads();  // A: wave_hist zeroed, partial column sums published
 
+    uint32_t rank[ITEMS];
     const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; i++) {
@@ -156,37 +215,81 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
         const int leader = valid ? (__ffsll((long long)peers) - 1) : 0;
         uint32_t old = 0;
         if (valid && (int)lane == leader) {
-            old = wave_hist[wid][digit];
-            wave_hist[wid][digit] = old + cnt;
+            old = L.wave_hist[wid][digit];
+            L.wave_hist[wid][digit] = old + cnt;
         }
         old = __shfl(old, leader, 64);
         rank[i] = old + below;
         __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    {
+    __syncthreads();  // B: every wave's digit counts are final
+    // Threads 0..255 (digit d): 16-wave combine (wave_hist[w][d] <- keys of digit d in earlier waves of the tile),
+    // the tile's count of d, and the global sums; then both exclusive scans over the digits behind one pair of
+    // barriers: (#keys with a smaller digit anywhere) and (start of the digit's run inside the tile).
+    uint32_t tile_cnt = 0;
+    if (threadIdx.x < kRadix) {
         const uint32_t d = threadIdx.x;
-        uint32_t run = 0;
 #pragma unroll
         for (uint32_t w = 0; w < kSortWaves; w++) {
-            const uint32_t t = wave_hist[w][d];
-            wave_hist[w][d] = run;
-            run += t;
+            const uint32_t t = L.wave_hist[w][d];
+            L.wave_hist[w][d] = tile_cnt;
+            tile_cnt += t;
+        }
+        if (FUSED) {
+            glob_tot = (L.part_all[0][d] + L.part_all[1][d]) + (L.part_all[2][d] + L.part_all[3][d]);
+            glob_base = (L.part[0][d] + L.part[1][d]) + (L.part[2][d] + L.part[3][d]);
         }
     }
-    __syncthreads();
+    uint32_t smaller = glob_tot, run_start = tile_cnt;
+    block_excl_scan256_pair(smaller, run_start, L.wave_tot2);
+    if (threadIdx.x < kRadix) {
+        L.digit_base[threadIdx.x] = smaller + glob_base;
+        L.tile_start[threadIdx.x] = run_start;
+    }
+    __syncthreads();  // C
+    if (!kReorder) {
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            const uint32_t idx = chunk + i * kWave + lane;
+            if (idx < n) {
+                const uint32_t digit = (key[i] >> shift) & mask;
+                const uint32_t pos = L.digit_base[digit] + L.wave_hist[wid][digit] + rank[i];
+                keys_out[pos] = key[i];
+                vals_out[pos] = val[i];
+            }
+        }
+        return;
+    }
+    // reorder by digit in LDS (stable: wave order, then rank inside the wave) ...
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; i++) {
         const uint32_t idx = chunk + i * kWave + lane;
         if (idx < n) {
             const uint32_t digit = (key[i] >> shift) & mask;
-            const uint32_t pos = digit_base[digit] + wave_hist[wid][digit] + rank[i];
-            keys_out[pos] = key[i];
-            vals_out[pos] = val[i];
+            const uint32_t lp = L.tile_start[digit] + L.wave_hist[wid][digit] + rank[i];
+            L.keys[lp] = key[i];
+            L.vals[lp] = val[i];
+        }
+    }
+    __syncthreads();
+    // ... and write out: position lp of the reordered tile belongs to the run of its digit, so consecutive lanes
+    // write consecutive global addresses (round 1 scattered one dword per lane into 256 runs: 2.1x write
+    // amplification at the HBM counters)
+    const uint32_t tile_n = min(kTileKeys, n - tile_base);
+#pragma unroll
+    for (uint32_t i = 0; i < ITEMS; i++) {
+        const uint32_t lp = i * kSortThreads + threadIdx.x;
+        if (lp < tile_n) {
+            const uint32_t k = L.keys[lp];
+            const uint32_t digit = (k >> shift) & mask;
+            const uint32_t pos = L.digit_base[digit] + (lp - L.tile_start[digit]);
+            keys_out[pos] = k;
+            vals_out[pos] = L.vals[lp];
         }
     }
 }
 
+template <bool FUSED>
 __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ d_n,
@@ -195,13 +298,10 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
     const uint32_t n = min(*d_n, max_n);
     const uint32_t items = sort_items(n);
     if ((uint64_t)blockIdx.x * kSortThreads * items >= n) return;
-
-    __shared__ uint32_t wave_hist[kSortWaves][kRadix];
-    __shared__ uint32_t digit_base[kRadix];
-    __shared__ uint32_t wave_tot[kSortWaves];
-#define BRUSH_DOWN(K)                                                                                        \
-    downsweep_body<K>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, counts, totals, max_tiles, wave_hist, \
-                      digit_base, wave_tot)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    DownLds &L = *reinterpret_cast<DownLds *>(lds_raw);
+#define BRUSH_DOWN(K) \
+    downsweep_body<FUSED, K>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, counts, totals, max_tiles, L)
     switch (items) {  // block-uniform
         case 1: BRUSH_DOWN(1); break;
         case 2: BRUSH_DOWN(2); break;
@@ -240,6 +340,18 @@ SortWs carve_sort(void *ws, uint32_t max_n) {
     return w;
 }
 
+// The downsweep needs more LDS than the 64 KiB a kernel gets by default: opt in once per process.
+hipError_t enable_big_lds() {
+    static const hipError_t st = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLds));
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLds));
+    }();
+    return st;
+}
+
 }  // namespace
 
 size_t sort_workspace_bytes(uint32_t max_n) { return carve_sort(nullptr, max_n).bytes; }
@@ -252,10 +364,13 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
     const uint32_t total_bits = 4u * ((bits + 3u) / 4u);  // brush-sort/src/lib.rs:58
     const uint32_t passes = (total_bits + 7u) / 8u;
     if (passes == 0) {
-        hipLaunchKernelGGL(k_sort_copy, dim3(min(w.max_tiles, 2048u)), dim3(256), 0, s, keys_in, vals_in,
+        hipLaunchKernelGGL(k_sort_copy, dim3(min(w.max_tiles * 4u, 2048u)), dim3(256), 0, s, keys_in, vals_in,
                            keys_out, vals_out, d_n, max_n);
         return hipGetLastError();
     }
+    const hipError_t lds = enable_big_lds();
+    if (lds != hipSuccess) return lds;
+    const bool fused = w.max_tiles <= kFusedMaxTiles;
     const uint32_t *src_k = keys_in, *src_v = vals_in;
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t shift = p * 8u;
@@ -264,12 +379,18 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
         const bool to_out = ((passes - 1 - p) % 2u) == 0;
         uint32_t *dst_k = to_out ? keys_out : w.tmp_keys;
         uint32_t *dst_v = to_out ? vals_out : w.tmp_vals;
-        hipLaunchKernelGGL(k_sort_upsweep, dim3(w.max_tiles), dim3(kSortThreads), 0, s, src_k, d_n, max_n, shift,
-                           mask, w.counts, w.max_tiles);
-        hipLaunchKernelGGL(k_sort_scan, dim3(kRadix), dim3(256), 0, s, w.counts, d_n, max_n, w.max_tiles,
-                           w.totals);
-        hipLaunchKernelGGL(k_sort_downsweep, dim3(w.max_tiles), dim3(kSortThreads), 0, s, src_k, src_v, dst_k,
-                           dst_v, d_n, max_n, shift, mask, w.counts, w.totals, w.max_tiles);
+        if (fused) {
+            hipLaunchKernelGGL(k_sort_upsweep<true>, dim3(w.max_tiles), dim3(kSortThreads), 0, s, src_k, d_n, max_n,
+                               shift, mask, w.counts, w.max_tiles);
+            hipLaunchKernelGGL(k_sort_downsweep<true>, dim3(w.max_tiles), dim3(kSortThreads), sizeof(DownLds), s, src_k,
+                               src_v, dst_k, dst_v, d_n, max_n, shift, mask, w.counts, w.totals, w.max_tiles);
+        } else {
+            hipLaunchKernelGGL(k_sort_upsweep<false>, dim3(w.max_tiles), dim3(kSortThreads), 0, s, src_k, d_n, max_n,
+                               shift, mask, w.counts, w.max_tiles);
+            hipLaunchKernelGGL(k_sort_scan, dim3(kRadix), dim3(256), 0, s, w.counts, d_n, max_n, w.max_tiles, w.totals);
+            hipLaunchKernelGGL(k_sort_downsweep<false>, dim3(w.max_tiles), dim3(kSortThreads), sizeof(DownLds), s,
+                               src_k, src_v, dst_k, dst_v, d_n, max_n, shift, mask, w.counts, w.totals, w.max_tiles);
+        }
         src_k = dst_k;
         src_v = dst_v;
     }

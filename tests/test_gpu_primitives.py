@@ -60,7 +60,8 @@ def test_sorting_big_clustered(dev):
 
 
 @pytest.mark.parametrize("n,bits", [(1, 32), (63, 32), (64, 8), (4096, 13), (4097, 13), (100000, 10), (100000, 4),
-                                    (100000, 1), (1 << 20, 32), (3000000, 16), (5000, 0)])
+                                    (100000, 1), (1 << 20, 32), (3000000, 16), (5000, 0), (65536, 32), (65537, 32),
+                                    (12_000_000, 16)])  # the last one: > 512 tiles of 16384 keys, the 3-launch shape
 def test_sort_matches_oracle(dev, n, bits):
     """Stability and the 'low 4*ceil(bits/4) bits only' rule vs the oracle, ragged sizes."""
     rng = np.random.default_rng(n + bits)
