@@ -44,6 +44,7 @@ class BrushAux(C.Structure):
         ("compact_from_global_gid", C.c_void_p),
         ("overflow", C.c_void_p),
         ("max_intersects", C.c_uint32),
+        ("isect_unsorted_pos", C.c_void_p),  # deterministic mode only (NULL otherwise)
     ]
 
 
@@ -85,8 +86,11 @@ _SYMBOLS = [
     ("brush_render_forward_rgba8", C.c_int,
      [C.POINTER(BrushUniforms), _P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(BrushAux), _P,
       C.c_size_t, _P]),
+    ("brush_deterministic", C.c_int, []),
     ("brush_bwd_workspace_size", C.c_int,
      [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
+    ("brush_bwd_workspace_size_ex", C.c_int,
+     [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
     ("brush_render_backward", C.c_int,
      [C.POINTER(BrushUniforms), C.POINTER(BrushAux), _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P,
       _P, _P, _P, C.c_size_t, _P]),

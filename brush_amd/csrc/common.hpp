@@ -17,6 +17,12 @@ constexpr uint32_t kNumVisibleWord = 25;                // render.rs:145-149
 // Compact-order gradient rows of the backward: [v_xy(2) v_conic(3) v_rgb(3) v_opac(1) pad(3)].
 constexpr uint32_t kCompactStride = 12;
 
+// BRUSH_DETERMINISTIC=1 (read once per process): the compositing backward writes one gradient row per
+// intersection instead of float atomics and the rows are summed per splat in a fixed order, so gradients are
+// bitwise reproducible run to run; the forward then also records where every sorted intersection sat before
+// the tile sort (BrushAux::isect_unsorted_pos).
+bool deterministic_mode();
+
 // Records the failing hipError_t for brush_last_hip_error().
 void set_last_hip_error(int e);
 
@@ -71,6 +77,7 @@ hipError_t scan_launch(const uint32_t *in, uint32_t *out, uint32_t n, const uint
 
 // radix_sort.hip
 size_t sort_workspace_bytes(uint32_t max_n);
+// vals_in == nullptr sorts the positions 0..n-1 themselves (argsort proper).
 hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
                        uint32_t *vals_out, const uint32_t *d_n, uint32_t max_n, uint32_t bits,
                        void *ws, hipStream_t s);

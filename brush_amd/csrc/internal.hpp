@@ -29,8 +29,10 @@ hipError_t launch_project_visible(const ViewParams &vp, const float *proj_global
 hipError_t launch_map_intersects(const ViewParams &vp, const float *projected, const uint32_t *cum_tiles_hit,
                                  const uint32_t *num_visible, uint32_t cap, uint32_t *tile_ids, uint32_t *gids,
                                  const WalkWs &walk, hipStream_t s);
+// perm / gid_unsorted / gid_sorted: deterministic mode only (nullptr otherwise), see k_tile_bin_edges.
 hipError_t launch_tile_bin_edges(const uint32_t *sorted_tile_ids, const uint32_t *num_intersections,
-                                 uint32_t cap, uint32_t *tile_bins, hipStream_t s);
+                                 uint32_t cap, uint32_t *tile_bins, const uint32_t *perm,
+                                 const uint32_t *gid_unsorted, uint32_t *gid_sorted, hipStream_t s);
 
 // rasterize.hip
 hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
@@ -41,6 +43,8 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
                                      const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
                                      const float *projected, const uint32_t *final_index,
                                      const float *out_img, const float *v_out, float *v_compact,
+                                     const uint32_t *unsorted_pos /* deterministic mode, else nullptr */,
+                                     float *rows /* deterministic mode: [max_intersects][12], else nullptr */,
                                      hipStream_t s);
 
 // project_bwd.hip
@@ -55,18 +59,28 @@ struct AdamFuse {
     float *grad_2d_accum, *xy_grad_counts;                 // optional [N]: refinement statistics (train.rs:284-316)
     float half_w, half_h;
 };
+// Deterministic mode: where a splat's compact-order sums come from (see project_bwd.hip); partials == nullptr
+// selects the default atomic accumulators in v_compact.
+struct DetSumsArgs {
+    const uint32_t *cum_tiles_hit = nullptr;
+    const uint32_t *num_intersections = nullptr;
+    const float *partials = nullptr;
+    uint32_t cap = 0;
+};
+hipError_t launch_sum_isect_rows(const float *rows, const uint32_t *num_intersections, const uint32_t *cum_tiles_hit,
+                                 uint32_t cap, float *v_compact, float *partials, hipStream_t s);
 hipError_t launch_project_backward(const ViewParams &vp, const float *means, const float *log_scales,
                                    const float *quats, const float *raw_opac,
                                    const uint32_t *compact_from_global, const float *v_compact,
                                    float *v_means, float *v_xy,
                                    float *v_scales, float *v_quats, float *v_sh, float *v_opac,
-                                   const AdamFuse *adam, hipStream_t s);
+                                   const AdamFuse *adam, const DetSumsArgs &det, hipStream_t s);
 // View-sharded data parallelism (project_bwd.hip): per-view 64-byte gradient records, their index by global id and
 // the deterministic per-splat sum over views (dense arrays, or straight into the Adam update when adam != nullptr).
 hipError_t launch_project_backward_records(const ViewParams &vp, const float *means, const float *log_scales,
                                            const float *quats, const float *raw_opac, const uint32_t *num_visible,
                                            const uint32_t *global_from_compact, const float *v_compact,
-                                           float *records, uint32_t max_rows, hipStream_t s);
+                                           float *records, uint32_t max_rows, const DetSumsArgs &det, hipStream_t s);
 hipError_t launch_reduce_view_records(const float *records, uint32_t num_views, uint32_t rows_per_view,
                                       const uint32_t *view_rows, const float *campos, const float *means, uint32_t n,
                                       uint32_t sh_degree, uint32_t *index, float *v_means, float *v_scales,

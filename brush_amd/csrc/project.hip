@@ -685,12 +685,18 @@ __global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, cons
 
 // ---- GetTileBinEdges -----------------------------------------------------------------------
 // get_tile_bin_edges.wgsl:15-42
+// perm != nullptr (deterministic mode): the tile sort carried the PRE-SORT positions as values; the compact gid
+// of sorted intersection i is then gathered from the unsorted list here.
 __global__ __launch_bounds__(kThreads) void k_tile_bin_edges(const uint32_t *__restrict__ sorted_tile_ids,
                                                              const uint32_t *__restrict__ num_intersections,
-                                                             uint32_t *__restrict__ tile_bins) {
+                                                             uint32_t *__restrict__ tile_bins,
+                                                             const uint32_t *__restrict__ perm,
+                                                             const uint32_t *__restrict__ gid_unsorted,
+                                                             uint32_t *__restrict__ gid_sorted) {
     const uint32_t I = *num_intersections;
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < I; i += gridDim.x * kThreads) {
         const uint32_t cur = sorted_tile_ids[i];
+        if (perm) gid_sorted[i] = gid_unsorted[perm[i]];
         if (i == I - 1) tile_bins[cur * 2 + 1] = I;
         if (i == 0) {
             tile_bins[cur * 2 + 0] = 0;
@@ -780,9 +786,10 @@ hipError_t launch_map_intersects(const ViewParams &vp, const float *projected, c
 }
 
 hipError_t launch_tile_bin_edges(const uint32_t *sorted_tile_ids, const uint32_t *num_intersections,
-                                 uint32_t cap, uint32_t *tile_bins, hipStream_t s) {
+                                 uint32_t cap, uint32_t *tile_bins, const uint32_t *perm,
+                                 const uint32_t *gid_unsorted, uint32_t *gid_sorted, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_bin_edges, dim3(stride_grid(cap)), dim3(kThreads), 0, s, sorted_tile_ids,
-                       num_intersections, tile_bins);
+                       num_intersections, tile_bins, perm, gid_unsorted, gid_sorted);
     return hipGetLastError();
 }
 

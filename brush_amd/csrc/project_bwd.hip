@@ -153,6 +153,91 @@ __device__ __forceinline__ void splat_projection_vjp(const ViewParams &vp, const
     quat_to_rotmat_vjp(quat, v_R, o_quat);
 }
 
+// Deterministic mode (BRUSH_DETERMINISTIC=1): where the compact-order sums of splat c come from.
+//   rows     [I][12]   one row per intersection in emission order (grouped by splat), written by the compositing
+//                      backward: [9 sums | compact gid | 0 | 0]
+//   k_sum_isect_rows   one lane per row, segmented scan inside each 64-row chunk: a splat whose rows lie inside one
+//                      chunk gets its sum in v_compact[c]; a splat that crosses chunk borders leaves partial sums
+//                      partials[chunk][0] (rows of a splat that began in an earlier chunk) / [1] (rows of a splat
+//                      that continues into the next chunk), which its consumer adds in chunk order.
+// Same rows, same tree, same order every run: bitwise reproducible, no atomics, no zero-fill.
+struct DetSums {
+    const uint32_t *cum_tiles_hit;      // [N] inclusive (aux)
+    const uint32_t *num_intersections;  // [1]
+    const float *partials;              // [ceil(cap / 64)][2][12]; nullptr = atomic mode
+    uint32_t cap;
+};
+
+__device__ __forceinline__ void load_compact_sums(const float *__restrict__ v_compact, const DetSums &det, uint32_t c,
+                                                  float4 &r0, float4 &r1, float4 &r2) {
+    const float4 *row = reinterpret_cast<const float4 *>(v_compact) + (size_t)c * (kCompactStride / 4);
+    if (!det.partials) {
+        r0 = row[0], r1 = row[1], r2 = row[2];
+        return;
+    }
+    const uint32_t I = min(*det.num_intersections, det.cap);
+    const uint32_t u0 = c ? min(det.cum_tiles_hit[c - 1], I) : 0u, u1 = min(det.cum_tiles_hit[c], I);
+    r0 = r1 = r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u1 <= u0) return;  // no intersection survived (exact tile test / capacity): zero gradient
+    const uint32_t k0 = u0 / kWave, k1 = (u1 - 1u) / kWave;
+    if (k0 == k1) {
+        r0 = row[0], r1 = row[1], r2 = row[2];
+        return;
+    }
+    for (uint32_t k = k0; k <= k1; k++) {  // chunk order
+        const float4 *p = reinterpret_cast<const float4 *>(det.partials) + ((size_t)k * 2 + (k == k0 ? 1 : 0)) * 3;
+        const float4 a = p[0], b = p[1], d = p[2];
+        r0.x += a.x, r0.y += a.y, r0.z += a.z, r0.w += a.w;
+        r1.x += b.x, r1.y += b.y, r1.z += b.z, r1.w += b.w;
+        r2.x += d.x;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_sum_isect_rows(const float4 *__restrict__ rows,
+                                                             const uint32_t *__restrict__ num_intersections,
+                                                             const uint32_t *__restrict__ cum_tiles_hit, uint32_t cap,
+                                                             float4 *__restrict__ v_compact,
+                                                             float4 *__restrict__ partials) {
+    const uint32_t I = min(*num_intersections, cap);
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t waves = gridDim.x * (kThreads / kWave);
+    for (uint32_t k = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; (uint64_t)k * kWave < I; k += waves) {
+        const uint32_t base = k * kWave, u = base + lane;
+        const bool valid = u < I;
+        float v[kCompactStride];
+        uint32_t c = 0, first = lane, last = lane;
+        bool starts_here = true, ends_here = true;
+#pragma unroll
+        for (uint32_t i = 0; i < kCompactStride; i++) v[i] = 0.f;
+        if (valid) {
+            const float4 a = rows[(size_t)u * 3], b = rows[(size_t)u * 3 + 1], d = rows[(size_t)u * 3 + 2];
+            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w, v[8] = d.x;
+            c = __float_as_uint(d.y);
+            const uint32_t u0 = c ? min(cum_tiles_hit[c - 1], I) : 0u, u1 = min(cum_tiles_hit[c], I);
+            starts_here = u0 >= base;
+            ends_here = u1 <= base + kWave;
+            first = max(u0, base) - base;
+            last = min(u1, base + kWave) - 1u - base;
+        }
+        // inclusive scan inside the segment [first, last] (lanes of one splat are contiguous)
+#pragma unroll
+        for (uint32_t dist = 1; dist < kWave; dist <<= 1) {
+#pragma unroll
+            for (uint32_t i = 0; i < 9; i++) {
+                const float up = __shfl_up(v[i], dist, 64);
+                if (lane >= first + dist) v[i] += up;
+            }
+        }
+        if (valid && lane == last) {
+            float4 *dst = (starts_here && ends_here) ? v_compact + (size_t)c * 3
+                                                     : partials + ((size_t)k * 2 + (starts_here ? 1 : 0)) * 3;
+            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+            dst[2] = make_float4(v[8], 0.f, 0.f, 0.f);
+        }
+    }
+}
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 // Streaming 16-byte accesses: data that is touched once per step and is far larger than the caches.
 __device__ __forceinline__ float4 nt_load4(const float *p) {
@@ -331,7 +416,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     const float *raw_opac, const uint32_t *__restrict__ compact_from_global,
     const float *__restrict__ v_compact, float *__restrict__ v_means, float *__restrict__ v_xy,
     float *__restrict__ v_scales, float *__restrict__ v_quats, float *__restrict__ v_sh,
-    float *__restrict__ v_opac, AdamFuse af) {
+    float *__restrict__ v_opac, AdamFuse af, DetSums det) {
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
     constexpr uint32_t kRow = ncoef * 3;                 // floats per v_sh row
     constexpr uint32_t kRowPad = kRow | 1u;              // odd LDS row stride: conflict-free column access
@@ -377,8 +462,8 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     for (uint32_t k = 0; k < ncoef; k++) Y[k] = 0.f;
 
     if (c != kInvalid) {
-        const float4 *row = reinterpret_cast<const float4 *>(v_compact) + (size_t)c * (kCompactStride / 4);
-        const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+        float4 r0, r1, r2;
+        load_compact_sums(v_compact, det, c, r0, r1, r2);
         const float vxy[2] = {r0.x, r0.y};
         const float vconic[3] = {r0.z, r0.w, r1.x};
         vcol[0] = r1.y;
@@ -454,12 +539,12 @@ __global__ __launch_bounds__(kThreads) void k_project_backward_records(
     ViewParams vp, const float *__restrict__ means, const float *__restrict__ log_scales,
     const float *__restrict__ quats, const float *__restrict__ raw_opac, const uint32_t *__restrict__ num_visible,
     const uint32_t *__restrict__ global_from_compact, const float *__restrict__ v_compact,
-    float4 *__restrict__ records, uint32_t max_rows, float half_w, float half_h) {
+    float4 *__restrict__ records, uint32_t max_rows, float half_w, float half_h, DetSums det) {
     const uint32_t V = min(min(*num_visible, vp.total_splats), max_rows);
     for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < V; c += gridDim.x * kThreads) {
         const uint32_t g = global_from_compact[c];
-        const float4 *row = reinterpret_cast<const float4 *>(v_compact) + (size_t)c * (kCompactStride / 4);
-        const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+        float4 r0, r1, r2;
+        load_compact_sums(v_compact, det, c, r0, r1, r2);
         const float vxy[2] = {r0.x, r0.y};
         const float vconic[3] = {r0.z, r0.w, r1.x};
         const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
@@ -564,20 +649,21 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
                                    const float *quats, const float *raw_opac,
                                    const uint32_t *compact_from_global, const float *v_compact, float *v_means,
                                    float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
-                                   const AdamFuse *adam, hipStream_t s) {
+                                   const AdamFuse *adam, const DetSumsArgs &dargs, hipStream_t s) {
     if (vp.total_splats == 0) return hipSuccess;
     const dim3 grid(ceil_div(vp.total_splats, kThreads)), block(kThreads);
     AdamFuse af{};
     if (adam) af = *adam;
+    const DetSums det{dargs.cum_tiles_hit, dargs.num_intersections, dargs.partials, dargs.cap};
 #define BRUSH_LAUNCH_PB(D)                                                                                      \
     if (adam)                                                                                                   \
         hipLaunchKernelGGL((k_project_backward<D, true>), grid, block, 0, s, vp, means, log_scales, quats,      \
                            raw_opac, compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats, v_sh,    \
-                           v_opac, af);                                                                         \
+                           v_opac, af, det);                                                                    \
     else                                                                                                        \
         hipLaunchKernelGGL((k_project_backward<D, false>), grid, block, 0, s, vp, means, log_scales, quats,     \
                            raw_opac, compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats, v_sh,    \
-                           v_opac, af)
+                           v_opac, af, det)
     switch (vp.sh_degree) {
         case 0: BRUSH_LAUNCH_PB(0); break;
         case 1: BRUSH_LAUNCH_PB(1); break;
@@ -592,13 +678,14 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
 hipError_t launch_project_backward_records(const ViewParams &vp, const float *means, const float *log_scales,
                                            const float *quats, const float *raw_opac, const uint32_t *num_visible,
                                            const uint32_t *global_from_compact, const float *v_compact,
-                                           float *records, uint32_t max_rows, hipStream_t s) {
+                                           float *records, uint32_t max_rows, const DetSumsArgs &dargs, hipStream_t s) {
     if (vp.total_splats == 0 || max_rows == 0) return hipSuccess;
     const uint32_t rows = min(vp.total_splats, max_rows);
+    const DetSums det{dargs.cum_tiles_hit, dargs.num_intersections, dargs.partials, dargs.cap};
     hipLaunchKernelGGL(k_project_backward_records, dim3(min(ceil_div(rows, kThreads), 2048u)), dim3(kThreads), 0, s, vp,
                        means, log_scales, quats, raw_opac, num_visible, global_from_compact, v_compact,
                        reinterpret_cast<float4 *>(records), max_rows, (float)vp.img_size[0] / 2.0f,
-                       (float)vp.img_size[1] / 2.0f);
+                       (float)vp.img_size[1] / 2.0f, det);
     return hipGetLastError();
 }
 
@@ -629,6 +716,16 @@ hipError_t launch_reduce_view_records(const float *records, uint32_t num_views, 
         default: BRUSH_LAUNCH_RV(4); break;
     }
 #undef BRUSH_LAUNCH_RV
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_isect_rows(const float *rows, const uint32_t *num_intersections, const uint32_t *cum_tiles_hit,
+                                 uint32_t cap, float *v_compact, float *partials, hipStream_t s) {
+    if (cap == 0) return hipSuccess;
+    const uint32_t chunks = ceil_div(cap, kWave);
+    hipLaunchKernelGGL(k_sum_isect_rows, dim3(min(ceil_div(chunks, kThreads / kWave), 4096u)), dim3(kThreads), 0, s,
+                       reinterpret_cast<const float4 *>(rows), num_intersections, cum_tiles_hit, cap,
+                       reinterpret_cast<float4 *>(v_compact), reinterpret_cast<float4 *>(partials));
     return hipGetLastError();
 }
 

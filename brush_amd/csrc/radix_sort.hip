@@ -165,7 +165,7 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
     for (uint32_t i = 0; i < ITEMS; i++) {
         const uint32_t idx = chunk + i * kWave + lane;
         key[i] = idx < n ? keys_in[idx] : 0u;
-        val[i] = idx < n ? vals_in[idx] : 0u;
+        val[i] = idx < n ? (vals_in ? vals_in[idx] : idx) : 0u;  // vals_in == nullptr: the positions themselves
     }
     // FUSED: counts[t][d]; thread (quarter qt, digit d) sums the rows t = qt, qt+4, ... of the ACTUAL tiles:
     // keys of digit d in earlier tiles / in all tiles.
@@ -318,7 +318,7 @@ __global__ void k_sort_copy(const uint32_t *__restrict__ keys_in, const uint32_t
     const uint32_t n = min(*d_n, max_n);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         keys_out[i] = keys_in[i];
-        vals_out[i] = vals_in[i];
+        vals_out[i] = vals_in ? vals_in[i] : i;
     }
 }
 

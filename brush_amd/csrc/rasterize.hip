@@ -589,12 +589,21 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
 // skipped by scalar branches.  Under the per-pixel `if` the updates are plain (exec-masked) moves,
 // no selects.  sigma is evaluated as 0.5 (dx gx + dy gy) with gx = a dx + b dy, gy = b dx + c dy,
 // which are the v_xy factors of rasterize_backwards.wgsl:260-263 as well.
-template <uint32_t NQ>
+//
+// DET (deterministic mode, NQ = 4 only: one wave per tile, so every intersection has exactly one producer):
+// instead of adding to the splat's compact row with float atomics, the wave STORES one 48-byte row per
+// intersection, [9 sums | compact gid | 0 | 0], at the position the intersection had before the tile sort
+// (`unsorted_pos`, grouped by splat); intersections it does not walk get zero rows.  k_sum_isect_rows then adds a
+// splat's rows in that fixed order.
+template <uint32_t NQ, bool DET>
 __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
     uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles, const uint32_t *__restrict__ gid_from_isect,
     const uint32_t *__restrict__ tile_bins, const float *__restrict__ projected,
     const uint32_t *__restrict__ final_index, const float *__restrict__ out_img,
-    const float *__restrict__ v_out, float *__restrict__ v_compact) {
+    const float *__restrict__ v_out, float *__restrict__ v_compact, const uint32_t *__restrict__ unsorted_pos,
+    float *__restrict__ rows) {
+    static_assert(!DET || NQ == 4, "deterministic mode: one wave per tile");
+    __shared__ uint32_t lds_pos_all[DET ? kTilesPerBlock : 1][kBatch];
     __shared__ QuadRec lds_all[kTilesPerBlock][kBatch];
     __shared__ uint32_t lds_gid_all[kTilesPerBlock][kBatch];
     __shared__ float acc_all[kTilesPerBlock][kBatch][12];  // 9 used; 48-byte rows keep b128 stores aligned
@@ -603,6 +612,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     QuadRec *lds = lds_all[wv];
     uint32_t *lds_gid = lds_gid_all[wv];
+    uint32_t *lds_pos = lds_pos_all[DET ? wv : 0];
     float(*acc)[12] = acc_all[wv];
     const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x, wv);
     const uint32_t tile_id = unit / kWavesPerTile, sub = unit % kWavesPerTile;
@@ -611,6 +621,14 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
     if (r1 <= r0) return;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t tx0 = (tile_id % tbx) * kTileWidth, ty0 = (tile_id / tbx) * kTileWidth;
+    // DET: zero rows (carrying their gid) for the intersections [lo, hi) this wave does not walk
+    auto zero_rows = [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo + lane; i < hi; i += kWave) {
+            float4 *r = reinterpret_cast<float4 *>(rows + (size_t)unsorted_pos[i] * kCompactStride);
+            r[0] = r[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            r[2] = make_float4(0.f, __uint_as_float(gid_from_isect[i]), 0.f, 0.f);
+        }
+    };
 
     // Per-quadrant pixel state (see k_rasterize_backward for D and K); pixels outside the image get
     // fin = -1 and never contribute.
@@ -641,6 +659,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) max_fin = max(max_fin, __shfl_xor(max_fin, d, 64));
     const uint32_t walk_end = min(r1, (uint32_t)(max_fin + 1));
+    if (DET) zero_rows(max(walk_end, r0), r1);
     if (walk_end <= r0) return;
 
     for (uint32_t batch_end = walk_end; batch_end > r0;) {
@@ -669,10 +688,15 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
             todo |= qm[s];
         }
         if (todo == 0ull) {
+            if (DET) zero_rows(batch_end - remaining, batch_end);
             batch_end -= remaining;
             continue;
         }
         wave_sync();  // previous batch fully flushed
+        if (DET && lane < remaining) {
+            lds_gid[lane] = cg_id;
+            lds_pos[lane] = unsorted_pos[batch_end - 1u - lane];
+        }
         if ((todo >> lane) & 1ull) {
             lds_gid[lane] = cg_id;
             lds[lane].a = make_float4(rec[0], rec[1], rec[2], rec[3]);
@@ -753,11 +777,20 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
         wave_sync();
         // Flush the staged records: one hardware float atomic per (wave, splat, component); consecutive
         // lanes take consecutive components of one splat.
-        for (uint32_t f = lane; f < remaining * kGradComps; f += kWave) {
-            const uint32_t t = f / kGradComps, k = f - t * kGradComps;
-            if ((flush_mask >> t) & 1ull) {
-                const float v = acc[t][k];
-                if (v != 0.0f) unsafeAtomicAdd(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], v);
+        if (DET) {
+            // one row per intersection of the batch (zeros where nothing contributed), 12 consecutive lanes per row
+            for (uint32_t f = lane; f < remaining * kCompactStride; f += kWave) {
+                const uint32_t t = f / kCompactStride, k = f - t * kCompactStride;
+                const float v = k < kGradComps ? acc[t][k] : (k == kGradComps ? __uint_as_float(lds_gid[t]) : 0.0f);
+                rows[(size_t)lds_pos[t] * kCompactStride + k] = v;
+            }
+        } else {
+            for (uint32_t f = lane; f < remaining * kGradComps; f += kWave) {
+                const uint32_t t = f / kGradComps, k = f - t * kGradComps;
+                if ((flush_mask >> t) & 1ull) {
+                    const float v = acc[t][k];
+                    if (v != 0.0f) unsafeAtomicAdd(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], v);
+                }
             }
         }
         batch_end -= remaining;
@@ -827,16 +860,24 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
                                      const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
                                      const float *projected, const uint32_t *final_index,
                                      const float *out_img, const float *v_out, float *v_compact,
-                                     hipStream_t s) {
+                                     const uint32_t *unsorted_pos, float *rows, hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
+    if (rows) {  // deterministic mode: one wave per tile, one stored row per intersection
+        const dim3 grid(ceil_div(ceil_div(tiles, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
+        hipLaunchKernelGGL((k_rasterize_backward_quad<4, true>), grid, block, 0, s, w, h, tbx, tiles,
+                           compact_gid_from_isect, tile_bins, projected, final_index, out_img, v_out, v_compact,
+                           unsorted_pos, rows);
+        return hipGetLastError();
+    }
     if (!legacy_raster()) {
         const uint32_t nq = backward_quadrants_per_wave(tiles);
         const uint32_t units = tiles * (4u / nq);
         const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
 #define BRUSH_RASTER_BWD(NQ)                                                                                     \
-    hipLaunchKernelGGL(k_rasterize_backward_quad<NQ>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, \
-                       tile_bins, projected, final_index, out_img, v_out, v_compact)
+    hipLaunchKernelGGL((k_rasterize_backward_quad<NQ, false>), grid, block, 0, s, w, h, tbx, tiles,                 \
+                       compact_gid_from_isect, tile_bins, projected, final_index, out_img, v_out, v_compact, nullptr, \
+                       nullptr)
         if (nq == 4) BRUSH_RASTER_BWD(4); else if (nq == 2) BRUSH_RASTER_BWD(2); else BRUSH_RASTER_BWD(1);
 #undef BRUSH_RASTER_BWD
         return hipGetLastError();

@@ -5,6 +5,7 @@
 // the caller's stream and never reads a count back to the host; unlike the reference it
 // performs no allocation (the caller passes one workspace) and needs no indirect-dispatch
 // helper kernels (kernels read the device-side counts and grid-stride).
+#include <stdlib.h>
 #include <string.h>
 
 #include "internal.hpp"
@@ -14,6 +15,14 @@ namespace brush {
 
 static thread_local int g_last_hip_error = 0;
 void set_last_hip_error(int e) { g_last_hip_error = e; }
+
+bool deterministic_mode() {
+    static const bool on = [] {
+        const char *e = getenv("BRUSH_DETERMINISTIC");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
 
 }  // namespace brush
 
@@ -91,19 +100,28 @@ FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap) {
 
 struct BwdWs {
     float *v_compact;  // [N, kCompactStride] compact-order gradient rows (first V used)
+    float *rows;       // deterministic mode: [cap, kCompactStride] one row per intersection, emission order
+    float *partials;   // deterministic mode: [ceil(cap / 64), 2, kCompactStride] chunk-border partial sums
     size_t bytes;
 };
 
-BwdWs carve_bwd(void *ws, uint32_t n) {
+BwdWs carve_bwd(void *ws, uint32_t n, uint32_t cap) {
     BwdWs b;
     Carver c(ws);
     const size_t nn = n ? n : 1;
     b.v_compact = c.take<float>(nn * kCompactStride);
+    b.rows = b.partials = nullptr;
+    if (deterministic_mode()) {
+        const size_t cc = cap ? cap : 1;
+        b.rows = c.take<float>(cc * kCompactStride);
+        b.partials = c.take<float>((size_t)ceil_div((uint32_t)cc, kWave) * 2 * kCompactStride);
+    }
     b.bytes = c.bytes();
     return b;
 }
 
 bool aux_ok(const BrushAux *a, bool need_final_index) {
+    if (a && deterministic_mode() && !a->isect_unsorted_pos) return false;
     return a && a->projected_splats && a->uniforms_buffer && a->num_intersections && a->num_visible &&
            (a->final_index || !need_final_index) && a->cum_tiles_hit && a->tile_bins &&
            a->compact_gid_from_isect && a->global_from_compact_gid && a->compact_from_global_gid && a->overflow;
@@ -153,12 +171,19 @@ extern "C" int brush_fwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint
     return BRUSH_OK;
 }
 
-extern "C" int brush_bwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree, size_t *bytes) {
+extern "C" int brush_deterministic(void) { return deterministic_mode() ? 1 : 0; }
+
+extern "C" int brush_bwd_workspace_size_ex(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
+                                           uint32_t max_intersects, size_t *bytes) {
     (void)w;
     (void)h;
     if (!bytes || sh_degree > 4) return BRUSH_ERR_INVALID_ARG;
-    *bytes = carve_bwd(nullptr, n).bytes;
+    *bytes = carve_bwd(nullptr, n, max_intersects).bytes;
     return BRUSH_OK;
+}
+
+extern "C" int brush_bwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree, size_t *bytes) {
+    return brush_bwd_workspace_size_ex(n, w, h, sh_degree, brush_default_max_intersects(n, w, h), bytes);
 }
 
 static int render_forward_impl(const BrushUniforms *h_uniforms, const float *means, const float *log_scales,
@@ -211,11 +236,17 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
     // Tile sort on bits = 32 - clz(num_tiles) (render.rs:227-237)
     uint32_t bits = 0;
     while (bits < 32 && (num_tiles >> bits) != 0) bits++;
-    BRUSH_HIP_CHECK(sort_launch(ws.tile_unsorted, ws.gid_unsorted, ws.tile_sorted, aux.compact_gid_from_isect,
-                                aux.num_intersections, cap, bits, ws.sort_ws, s));
+    // Deterministic mode: the sort carries the pre-sort positions (aux.isect_unsorted_pos) and the gids follow by
+    // a gather in the bin-edge kernel.
+    const bool det = deterministic_mode();
+    BRUSH_HIP_CHECK(sort_launch(ws.tile_unsorted, det ? nullptr : ws.gid_unsorted, ws.tile_sorted,
+                                det ? aux.isect_unsorted_pos : aux.compact_gid_from_isect, aux.num_intersections, cap,
+                                bits, ws.sort_ws, s));
     mark_fwd(s, 1 + BRUSH_STAGE_TILE_SORT);
     // GetTileBinEdges (render.rs:239-262)
-    BRUSH_HIP_CHECK(launch_tile_bin_edges(ws.tile_sorted, aux.num_intersections, cap, aux.tile_bins, s));
+    BRUSH_HIP_CHECK(launch_tile_bin_edges(ws.tile_sorted, aux.num_intersections, cap, aux.tile_bins,
+                                          det ? aux.isect_unsorted_pos : nullptr, ws.gid_unsorted,
+                                          aux.compact_gid_from_isect, s));
     mark_fwd(s, 1 + BRUSH_STAGE_TILE_BINS);
     // Rasterize (render.rs:267-307)
     BRUSH_HIP_CHECK(launch_rasterize(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
@@ -245,6 +276,36 @@ extern "C" int brush_render_forward_rgba8(const BrushUniforms *h_uniforms, const
 
 extern "C" uint32_t brush_rgba8_row_pitch(uint32_t width) { return (width + 63u) / 64u * 64u; }
 
+// RasterizeBackwards (render.rs:505-532): the compact-order sums of every visible splat.  Default: zero the
+// accumulators, add with hardware float atomics.  Deterministic mode: one stored row per intersection, then the
+// fixed-order per-splat sums (no zero-fill, no atomics).  Fills `det` for the consumer kernel.
+static int composite_backward(const BrushUniforms &u, const BrushAux &aux, const float *out_img, const float *v_out,
+                              uint32_t n, const BwdWs &ws, DetSumsArgs *det, hipStream_t s) {
+    const uint32_t w = u.img_size[0], h = u.img_size[1], tbx = u.tile_bounds[0], tby = u.tile_bounds[1];
+    if (ws.rows) {
+        mark_bwd(s, 1);  // no zero-fill stage in this mode
+        BRUSH_HIP_CHECK(launch_rasterize_backward(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
+                                                  aux.projected_splats, aux.final_index, out_img, v_out, ws.v_compact,
+                                                  aux.isect_unsorted_pos, ws.rows, s));
+        BRUSH_HIP_CHECK(launch_sum_isect_rows(ws.rows, aux.num_intersections, aux.cum_tiles_hit, aux.max_intersects,
+                                              ws.v_compact, ws.partials, s));
+        mark_bwd(s, 2);
+        det->cum_tiles_hit = aux.cum_tiles_hit;
+        det->num_intersections = aux.num_intersections;
+        det->partials = ws.partials;
+        det->cap = aux.max_intersects;
+        return BRUSH_OK;
+    }
+    // compact-order accumulators are atomically added to: zero the first V rows (render.rs:505-507)
+    BRUSH_HIP_CHECK(launch_zero_compact_grads(aux.num_visible, n, ws.v_compact, s));
+    mark_bwd(s, 1);
+    BRUSH_HIP_CHECK(launch_rasterize_backward(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
+                                              aux.projected_splats, aux.final_index, out_img, v_out, ws.v_compact,
+                                              nullptr, nullptr, s));
+    mark_bwd(s, 2);
+    return BRUSH_OK;
+}
+
 static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux *h_aux, const float *means,
                                 const float *log_scales, const float *quats, const float *raw_opacity, uint32_t n,
                                 const float *out_img, const float *v_out, float *v_means, float *v_xy,
@@ -255,28 +316,21 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
     if (n > 0 && (!means || !log_scales || !quats || !raw_opacity || !v_xy)) return BRUSH_ERR_INVALID_ARG;
     if (n > 0 && !adam && (!v_means || !v_scales || !v_quats || !v_sh || !v_opac)) return BRUSH_ERR_INVALID_ARG;
     const BrushAux &aux = *h_aux;
-    const BwdWs ws = carve_bwd(workspace, n);
+    const BwdWs ws = carve_bwd(workspace, n, aux.max_intersects);
     if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     BrushUniforms u = *h_uniforms;
     u.total_splats = n;
     const ViewParams vp = make_view_params(u, n);
-    const uint32_t w = u.img_size[0], h = u.img_size[1];
-    const uint32_t tbx = u.tile_bounds[0], tby = u.tile_bounds[1];
 
     mark_bwd(s, 0);
-    // compact-order accumulators are atomically added to: zero the first V rows (render.rs:505-507)
-    BRUSH_HIP_CHECK(launch_zero_compact_grads(aux.num_visible, n, ws.v_compact, s));
-    mark_bwd(s, 1);
-    // RasterizeBackwards (render.rs:515-532)
-    BRUSH_HIP_CHECK(launch_rasterize_backward(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
-                                              aux.projected_splats, aux.final_index, out_img, v_out,
-                                              ws.v_compact, s));
-    mark_bwd(s, 2);
+    DetSumsArgs det;
+    if (const int rc = composite_backward(u, aux, out_img, v_out, n, ws, &det, s)) return rc;
     // GatherGrads + ProjectBackwards fused, dense outputs written once (render.rs:534-594)
     BRUSH_HIP_CHECK(launch_project_backward(vp, means, log_scales, quats, raw_opacity, aux.compact_from_global_gid,
-                                            ws.v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac, adam, s));
+                                            ws.v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac, adam, det,
+                                            s));
     mark_bwd(s, 3);
     return BRUSH_OK;
 }
@@ -349,21 +403,18 @@ extern "C" int brush_render_backward_records(const BrushUniforms *h_uniforms, co
         return BRUSH_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(records) & 15) != 0) return BRUSH_ERR_INVALID_ARG;
     const BrushAux &aux = *h_aux;
-    const BwdWs ws = carve_bwd(workspace, n);
+    const BwdWs ws = carve_bwd(workspace, n, aux.max_intersects);
     if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     BrushUniforms u = *h_uniforms;
     u.total_splats = n;
     const ViewParams vp = make_view_params(u, n);
     mark_bwd(s, 0);
-    BRUSH_HIP_CHECK(launch_zero_compact_grads(aux.num_visible, n, ws.v_compact, s));
-    mark_bwd(s, 1);
-    BRUSH_HIP_CHECK(launch_rasterize_backward(u.img_size[0], u.img_size[1], u.tile_bounds[0], u.tile_bounds[1],
-                                              aux.compact_gid_from_isect, aux.tile_bins, aux.projected_splats,
-                                              aux.final_index, out_img, v_out, ws.v_compact, s));
-    mark_bwd(s, 2);
+    DetSumsArgs det;
+    if (const int rc = composite_backward(u, aux, out_img, v_out, n, ws, &det, s)) return rc;
     BRUSH_HIP_CHECK(launch_project_backward_records(vp, means, log_scales, quats, raw_opacity, aux.num_visible,
-                                                    aux.global_from_compact_gid, ws.v_compact, records, max_rows, s));
+                                                    aux.global_from_compact_gid, ws.v_compact, records, max_rows, det,
+                                                    s));
     mark_bwd(s, 3);
     return BRUSH_OK;
 }

@@ -242,7 +242,8 @@ class ViewExchange:
         n = means.shape[0]
         w, h = int(u.img_size[0]), int(u.img_size[1])
         nbytes = C.c_size_t()
-        _lib.check(l.brush_bwd_workspace_size(n, w, h, int(u.sh_degree), C.byref(nbytes)), "brush_bwd_workspace_size")
+        _lib.check(l.brush_bwd_workspace_size_ex(n, w, h, int(u.sh_degree), int(aux.max_intersects), C.byref(nbytes)),
+                   "brush_bwd_workspace_size_ex")
         if getattr(self, "_ws", None) is None or self._ws.numel() < nbytes.value:
             self._ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=self.device)
         s = aux._as_struct()

@@ -62,6 +62,8 @@ class RenderAux:
     compact_from_global_gid: torch.Tensor  # [N] i32 (-1 = not visible)
     overflow: torch.Tensor                 # [1] i32, 1 if intersections were truncated
     max_intersects: int = 0
+    # deterministic mode (BRUSH_DETERMINISTIC=1) only: pre-sort position of every sorted intersection
+    isect_unsorted_pos: Optional[torch.Tensor] = None
 
     def read_num_visible(self) -> int:
         """lib.rs:42-47 (a host readback; not on the hot path)."""
@@ -82,6 +84,7 @@ class RenderAux:
                      "compact_from_global_gid", "overflow"):
             setattr(s, name, getattr(self, name).data_ptr())
         s.max_intersects = int(self.max_intersects)
+        s.isect_unsorted_pos = None if self.isect_unsorted_pos is None else self.isect_unsorted_pos.data_ptr()
         return s
 
 
@@ -146,6 +149,7 @@ def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, ra
         compact_from_global_gid=_empty((nn,), i32, dev),
         overflow=_empty((1,), i32, dev),
         max_intersects=cap,
+        isect_unsorted_pos=_empty((cap,), i32, dev) if l.brush_deterministic() else None,
     )
     if row_pitch is not None:
         if not render_u32 or row_pitch < w:
@@ -209,7 +213,8 @@ def _backward_impl(u, aux: RenderAux, means, log_scales, quats, raw_opacity, nco
         "v_opac": seg("v_opac", (n,)), "v_sh": seg("v_sh", (n, ncoef, 3)), "v_xy": seg("v_xy", (n, 2)),
     }
     nbytes = C.c_size_t()
-    _lib.check(l.brush_bwd_workspace_size(n, w, h, int(u.sh_degree), C.byref(nbytes)), "brush_bwd_workspace_size")
+    _lib.check(l.brush_bwd_workspace_size_ex(n, w, h, int(u.sh_degree), int(aux.max_intersects), C.byref(nbytes)),
+               "brush_bwd_workspace_size_ex")
     ws = _empty((max(nbytes.value, 1),), torch.uint8, dev)
     v_out = v_out.contiguous()
     s = aux._as_struct()

@@ -84,6 +84,11 @@ typedef struct BrushAux {
                                           map_gaussian_to_intersects.wgsl:40) */
     uint32_t max_intersects;           /* capacity; reference: min(N*tiles, 128*65535)
                                           (render.rs:204-206) */
+    uint32_t *isect_unsorted_pos;      /* [max_intersects] or NULL.  Deterministic mode (BRUSH_DETERMINISTIC=1,
+                                          brush_deterministic()) only: position each sorted intersection had in
+                                          emission order (grouped by splat), written by the forward and used by
+                                          the backward to sum a splat's per-tile gradient rows in a fixed order.
+                                          Must be non-NULL in that mode, ignored otherwise. */
 } BrushAux;
 
 /* ---- introspection ------------------------------------------------------------------ */
@@ -138,8 +143,18 @@ int brush_render_forward_rgba8(const BrushUniforms *uniforms, const float *means
                                void *workspace, size_t workspace_bytes, brush_stream_t stream);
 
 /* ---- render backward ------------------------------------------------------------------ */
+/* 1 when the process runs with BRUSH_DETERMINISTIC=1: gradients are then bitwise reproducible run to run (one
+ * gradient row per intersection, summed per splat in a fixed order, instead of hardware float atomics whose
+ * arrival order is unspecified; the reference's CAS queue, rasterize_backwards.wgsl:276-301, has the same
+ * nondeterminism).  The mode needs BrushAux::isect_unsorted_pos and the larger workspace of
+ * brush_bwd_workspace_size_ex. */
+int brush_deterministic(void);
 int brush_bwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
                              size_t *bytes);
+/* As above with the intersection capacity explicit (the deterministic mode keeps 48 bytes per intersection);
+ * brush_bwd_workspace_size assumes brush_default_max_intersects(n, w, h). */
+int brush_bwd_workspace_size_ex(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree, uint32_t max_intersects,
+                                size_t *bytes);
 /* Gradients in the parent order of render.rs:420-427,598-624:
  * v_means[N,3] v_xy[N,2] (global order, pixel units) v_scales[N,3] (log-space)
  * v_quats[N,4] v_sh[N,C,3] v_opac[N] — dense, every element written, 0 for non-visible
