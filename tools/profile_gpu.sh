@@ -12,8 +12,8 @@ OUT=gpurun_out/prof_$TAG
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 mkdir -p "$OUT"
-BENCH_EAGER="bench.py --no-graph --steps 6 --warmup 2 --profile-steps 0 --train-steps 0 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/graph" -o kt -- python3 bench.py --train-steps 20 --no-cpu-baseline > "$OUT/bench_graph.json" 2> "$OUT/graph.err"
+BENCH_EAGER="bench.py --no-graph --steps 6 --warmup 2 --profile-steps 0 --train-steps 0 --no-cpu-baseline --no-extra"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/graph" -o kt -- python3 bench.py --train-steps 20 --no-cpu-baseline --no-extra > "$OUT/bench_graph.json" 2> "$OUT/graph.err"
 echo "graph trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/eager" -o kt -- python3 $BENCH_EAGER > "$OUT/bench_eager.json" 2> "$OUT/eager.err"
 echo "eager trace done"

@@ -75,9 +75,11 @@ for k in sorted(pmc):
 # stage-level sums (the keys bench.py looks up): bytes and VALU instructions per launch of the stage
 STAGES = {"project_cull": ["k_project_cull", "k_cull_scan", "k_compact"], "project_visible": ["k_project_visible", "k_walk_count"],
           "map_intersects": ["k_map_intersects"], "tile_bins": ["k_tile_bin_edges"],
-          "rasterize": ["k_rasterize"], "bwd_zero": ["k_zero_compact_grads"], "rasterize_bwd": ["k_rasterize_backward"],
-          "project_bwd": ["k_project_backward"]}
+          "rasterize": ["k_rasterize_quad", "k_rasterize"], "bwd_zero": ["k_zero_compact_grads"],
+          "rasterize_bwd": ["k_rasterize_backward_quad", "k_rasterize_backward"], "project_bwd": ["k_project_backward"],
+          "sort": ["k_sort_upsweep", "k_sort_scan", "k_sort_downsweep"]}
 traffic["valu_insts"] = {}
+traffic["_tag"] = tag
 for stage, ks in STAGES.items():
     b = [traffic["kernels"][k]["hbm_bytes_per_launch"] for k in ks if k in traffic["kernels"]]
     if b:
