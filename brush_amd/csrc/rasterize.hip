@@ -595,18 +595,18 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
 // intersection, [9 sums | compact gid | 0 | 0], at the position the intersection had before the tile sort
 // (`unsorted_pos`, grouped by splat); intersections it does not walk get zero rows.  k_sum_isect_rows then adds a
 // splat's rows in that fixed order.
-template <uint32_t NQ, bool DET>
-__global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
+template <uint32_t NQ, bool DET, uint32_t TPB>
+__global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
     uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles, const uint32_t *__restrict__ gid_from_isect,
     const uint32_t *__restrict__ tile_bins, const float *__restrict__ projected,
     const uint32_t *__restrict__ final_index, const float *__restrict__ out_img,
     const float *__restrict__ v_out, float *__restrict__ v_compact, const uint32_t *__restrict__ unsorted_pos,
     float *__restrict__ rows) {
     static_assert(!DET || NQ == 4, "deterministic mode: one wave per tile");
-    __shared__ uint32_t lds_pos_all[DET ? kTilesPerBlock : 1][kBatch];
-    __shared__ QuadRec lds_all[kTilesPerBlock][kBatch];
-    __shared__ uint32_t lds_gid_all[kTilesPerBlock][kBatch];
-    __shared__ float acc_all[kTilesPerBlock][kBatch][12];  // 9 used; 48-byte rows keep b128 stores aligned
+    __shared__ uint32_t lds_pos_all[DET ? TPB : 1][kBatch];
+    __shared__ QuadRec lds_all[TPB][kBatch];
+    __shared__ uint32_t lds_gid_all[TPB][kBatch];
+    __shared__ float acc_all[TPB][kBatch][12];  // 9 used; 48-byte rows keep b128 stores aligned
     constexpr uint32_t kWavesPerTile = 4u / NQ;
 
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
     uint32_t *lds_gid = lds_gid_all[wv];
     uint32_t *lds_pos = lds_pos_all[DET ? wv : 0];
     float(*acc)[12] = acc_all[wv];
-    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x, wv);
+    const uint32_t unit = ((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * TPB + wv;  // XCD-contiguous
     const uint32_t tile_id = unit / kWavesPerTile, sub = unit % kWavesPerTile;
     if (tile_id >= num_tiles) return;
     const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
 
     // Per-quadrant pixel state (see k_rasterize_backward for D and K); pixels outside the image get
     // fin = -1 and never contribute.
-    float pcx[NQ], pcy[NQ], T[NQ], K[NQ], D[NQ], vor[NQ], vog[NQ], vob[NQ];
+    float pcx[NQ], pcy[NQ], T[NQ], KD[NQ], vor[NQ], vog[NQ], vob[NQ];  // KD = K - D of k_rasterize_backward
     int32_t fin[NQ];
     int32_t max_fin = -1;
 #pragma unroll
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
             fin[s] = (int32_t)final_index[pix];
             vo = reinterpret_cast<const float4 *>(v_out)[pix];
         }
-        T[s] = T_final, K[s] = T_final * vo.w, D[s] = 0.0f;
+        T[s] = T_final, KD[s] = T_final * vo.w;
         vor[s] = vo.x, vog[s] = vo.y, vob[s] = vo.z;
         max_fin = max(max_fin, fin[s]);
     }
@@ -709,18 +709,24 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
         }
         wave_sync();
         const uint64_t flush_mask = todo;
-        while (todo != 0ull) {
-            const uint32_t t = (uint32_t)__builtin_ctzll(todo);
-            todo &= todo - 1ull;
+        // One record: its LDS row is read one record AHEAD (software pipeline, two register sets in turn), so the
+        // broadcast's latency is covered by the previous record's arithmetic instead of stalling the wave.
+        auto one_record = [&](const uint32_t t, const float4 a, const float4 b, const float opac) {
             const int32_t isect_id = (int32_t)(batch_end - 1u - t);
-            const float4 a = lds[t].a;
-            const float4 b = lds[t].b;
-            const float opac = lds[t].c.x;
             // Zeros the compiler cannot see through: every quadrant then accumulates in place under its
             // exec mask, instead of each path materialising its own set of nine zero registers.
             float g[kGradComps];
-#pragma unroll
-            for (uint32_t k = 0; k < kGradComps; k++) asm volatile("v_mov_b32 %0, 0" : "=v"(g[k]));
+            {
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                f2v z01, z23, z45, z67;
+                asm volatile("v_mov_b64 %0, 0" : "=v"(z01));
+                asm volatile("v_mov_b64 %0, 0" : "=v"(z23));
+                asm volatile("v_mov_b64 %0, 0" : "=v"(z45));
+                asm volatile("v_mov_b64 %0, 0" : "=v"(z67));
+                g[0] = z01.x, g[1] = z01.y, g[2] = z23.x, g[3] = z23.y;
+                g[4] = z45.x, g[5] = z45.y, g[6] = z67.x, g[7] = z67.y;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(g[8]));
+            }
             bool contributed = false;
 #pragma unroll
             for (uint32_t s = 0; s < NQ; s++) {
@@ -735,23 +741,26 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
                     // rasterize_backwards.wgsl:239-271
                     const float alpha = vmin(0.99f, alpha_u);  // 0.99 here, 0.999 in the forward (:239)
                     const float om = 1.0f - alpha;
-                    float ra = __builtin_amdgcn_rcpf(om);       // 1 - alpha >= 0.01: always finite
-                    ra = fmaf(fmaf(-om, ra, 1.0f), ra, ra);     // one Newton step
+                    // v_rcp_f32 is good to 1 ulp and 1 - alpha >= 0.01 (always finite); WGSL's own division is
+                    // specified to 2.5 ulp, so no refinement step
+                    const float ra = __builtin_amdgcn_rcpf(om);
                     const float Tn = T[s] * ra;
                     const float fac = alpha * Tn;
                     const float cv = fmaf(b.w, vob[s], fmaf(b.z, vog[s], b.y * vor[s]));
                     // v_alpha = (c*T - buffer*ra) . v_rgb + T_final*ra*v_a = T (c . v_rgb) + ra (K - D)
-                    const float v_alpha = fmaf(Tn, cv, ra * (K[s] - D[s]));
+                    const float v_alpha = fmaf(Tn, cv, ra * KD[s]);
                     T[s] = Tn;
-                    D[s] = fmaf(fac, cv, D[s]);
-                    const float vva = vis * v_alpha;  // v_opac term
-                    const float v_sigma = -opac * vva;
-                    const float hs = 0.5f * v_sigma;
-                    g[0] = fmaf(v_sigma, gx, g[0]);
-                    g[1] = fmaf(v_sigma, gy, g[1]);
-                    g[2] = fmaf(hs * dx, dx, g[2]);
-                    g[3] = fmaf(v_sigma * dx, dy, g[3]);
-                    g[4] = fmaf(hs * dy, dy, g[4]);
+                    KD[s] = fmaf(-fac, cv, KD[s]);
+                    // v_sigma = -opac vis v_alpha; the factors that are the same for every pixel (-opac, the conic
+                    // in gx / gy, the 1/2 of the conic terms) are applied once per record at the flush:
+                    //   g0 = sum vva dx, g1 = sum vva dy, g2..4 = sum vva (dx dx, dx dy, dy dy), g8 = sum vva
+                    const float vva = vis * v_alpha;
+                    const float wx = vva * dx, wy = vva * dy;
+                    g[0] += wx;
+                    g[1] += wy;
+                    g[2] = fmaf(wx, dx, g[2]);
+                    g[3] = fmaf(wx, dy, g[3]);
+                    g[4] = fmaf(wy, dy, g[4]);
                     g[5] = fmaf(fac, vor[s], g[5]);
                     g[6] = fmaf(fac, vog[s], g[6]);
                     g[7] = fmaf(fac, vob[s], g[7]);
@@ -773,22 +782,55 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward_quad(
                     if (lane == 63) acc[t][8] = s8;
                 }
             }
+        };
+        {
+            uint32_t tA = (uint32_t)__builtin_ctzll(todo), tB = tA;
+            float4 aA = lds[tA].a, bA = lds[tA].b, aB, bB;
+            float oA = lds[tA].c.x, oB;
+            for (;;) {
+                todo &= todo - 1ull;
+                tB = todo != 0ull ? (uint32_t)__builtin_ctzll(todo) : tA;
+                aB = lds[tB].a, bB = lds[tB].b, oB = lds[tB].c.x;
+                one_record(tA, aA, bA, oA);
+                if (todo == 0ull) break;
+                todo &= todo - 1ull;
+                tA = todo != 0ull ? (uint32_t)__builtin_ctzll(todo) : tB;
+                aA = lds[tA].a, bA = lds[tA].b, oA = lds[tA].c.x;
+                one_record(tB, aB, bB, oB);
+                if (todo == 0ull) break;
+            }
         }
         wave_sync();
         // Flush the staged records: one hardware float atomic per (wave, splat, component); consecutive
         // lanes take consecutive components of one splat.
+        // acc holds the raw pixel sums; the per-record factors (rasterize_backwards.wgsl:256-263):
+        //   v_xy = -opac (a S0 + b S1, b S0 + c S1), v_conic = -opac (S2 / 2, S3, S4 / 2), v_rgb, v_opac = S8
+        auto finish = [&](uint32_t t, uint32_t k) -> float {
+            const float v = acc[t][k];
+            if (k >= 5u) return v;
+            const float4 a = lds[t].a;
+            const float nopac = -lds[t].c.x;
+            if (k >= 2u) return (k == 3u ? nopac : 0.5f * nopac) * v;
+            const float other = acc[t][k ^ 1u];
+            return nopac * (k == 0u ? fmaf(a.z, v, a.w * other) : fmaf(lds[t].b.x, v, a.w * other));
+        };
         if (DET) {
             // one row per intersection of the batch (zeros where nothing contributed), 12 consecutive lanes per row
             for (uint32_t f = lane; f < remaining * kCompactStride; f += kWave) {
                 const uint32_t t = f / kCompactStride, k = f - t * kCompactStride;
-                const float v = k < kGradComps ? acc[t][k] : (k == kGradComps ? __uint_as_float(lds_gid[t]) : 0.0f);
+                float v = 0.0f;
+                if (k < kGradComps) {
+                    if ((flush_mask >> t) & 1ull) v = finish(t, k);
+                } else if (k == kGradComps) {
+                    v = __uint_as_float(lds_gid[t]);
+                }
                 rows[(size_t)lds_pos[t] * kCompactStride + k] = v;
             }
         } else {
             for (uint32_t f = lane; f < remaining * kGradComps; f += kWave) {
                 const uint32_t t = f / kGradComps, k = f - t * kGradComps;
                 if ((flush_mask >> t) & 1ull) {
-                    const float v = acc[t][k];
+                    const float v = finish(t, k);
                     if (v != 0.0f) unsafeAtomicAdd(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], v);
                 }
             }
@@ -863,25 +905,63 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
                                      const uint32_t *unsorted_pos, float *rows, hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
+    static const uint32_t tpb = [] {
+        const char *e = getenv("BRUSH_BWD_TPB");
+        const int v = e ? atoi(e) : 4;
+        return (v == 1 || v == 2 || v == 4) ? (uint32_t)v : 4u;
+    }();
+    // Waves per SIMD.  The kernel is bound by VALU issue once a SIMD holds 3+ waves, every wave lives for its whole
+    // tile and the tiles' lists are about equally long, so the launch proceeds in rounds of (SIMDs x k) waves and a
+    // partly filled last round costs as much as a full one: k in {3, 4, 5} is chosen to waste the least of the last
+    // round (1080p: 8160 waves on 1024 SIMDs, k = 4 -> 2 rounds, 152 us; k = 5 -> 1.6 rounds, 164 us; k = 3: 177 us).
+    // The registers allow 5 (4 in deterministic mode); fewer are enforced with unused dynamic LDS per workgroup.
+    static const uint32_t simds = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        return (uint32_t)cus * 4u;
+    }();
+    static const int forced_waves = [] {
+        const char *e = getenv("BRUSH_BWD_WAVES");
+        return e ? atoi(e) : 0;
+    }();
+    auto lds_pad_for = [&](uint32_t units, uint32_t max_k) -> uint32_t {
+        uint32_t best_k = max_k, best_cost = 0xFFFFFFFFu;
+        for (uint32_t k = max_k; k >= 3u; k--) {
+            const uint32_t cost = ceil_div(units, simds * k) * k;  // in wave-rounds per SIMD
+            if (cost < best_cost) best_cost = cost, best_k = k;
+        }
+        if (forced_waves >= 3 && forced_waves <= 5) best_k = (uint32_t)forced_waves;
+        // static LDS is ~6.3 KB per wave: 160 KB / (k waves x 4 SIMDs) per wave admits exactly k workgroups of 4 waves
+        return best_k >= 5u ? 0u : (best_k == 4u ? 2048u : 4096u);
+    };
+#define BRUSH_RASTER_BWD(NQ, DET, TPB, UNSORTED, ROWS)                                                            \
+    hipLaunchKernelGGL((k_rasterize_backward_quad<NQ, DET, TPB>), dim3(ceil_div(ceil_div(units, TPB), 8u) * 8u),  \
+                       dim3(TPB * kWave), lds_pad * TPB, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins, projected,   \
+                       final_index, out_img, v_out, v_compact, UNSORTED, ROWS)
+#define BRUSH_RASTER_BWD_TPB(NQ, DET, UNSORTED, ROWS)                   \
+    do {                                                                \
+        if (tpb == 1) BRUSH_RASTER_BWD(NQ, DET, 1, UNSORTED, ROWS);     \
+        else if (tpb == 2) BRUSH_RASTER_BWD(NQ, DET, 2, UNSORTED, ROWS); \
+        else BRUSH_RASTER_BWD(NQ, DET, 4, UNSORTED, ROWS);              \
+    } while (0)
     if (rows) {  // deterministic mode: one wave per tile, one stored row per intersection
-        const dim3 grid(ceil_div(ceil_div(tiles, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
-        hipLaunchKernelGGL((k_rasterize_backward_quad<4, true>), grid, block, 0, s, w, h, tbx, tiles,
-                           compact_gid_from_isect, tile_bins, projected, final_index, out_img, v_out, v_compact,
-                           unsorted_pos, rows);
+        const uint32_t units = tiles;
+        const uint32_t lds_pad = lds_pad_for(units, 4u);
+        BRUSH_RASTER_BWD_TPB(4, true, unsorted_pos, rows);
         return hipGetLastError();
     }
     if (!legacy_raster()) {
         const uint32_t nq = backward_quadrants_per_wave(tiles);
         const uint32_t units = tiles * (4u / nq);
-        const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
-#define BRUSH_RASTER_BWD(NQ)                                                                                     \
-    hipLaunchKernelGGL((k_rasterize_backward_quad<NQ, false>), grid, block, 0, s, w, h, tbx, tiles,                 \
-                       compact_gid_from_isect, tile_bins, projected, final_index, out_img, v_out, v_compact, nullptr, \
-                       nullptr)
-        if (nq == 4) BRUSH_RASTER_BWD(4); else if (nq == 2) BRUSH_RASTER_BWD(2); else BRUSH_RASTER_BWD(1);
-#undef BRUSH_RASTER_BWD
+        const uint32_t lds_pad = lds_pad_for(units, 5u);
+        if (nq == 4) BRUSH_RASTER_BWD_TPB(4, false, nullptr, nullptr);
+        else if (nq == 2) BRUSH_RASTER_BWD_TPB(2, false, nullptr, nullptr);
+        else BRUSH_RASTER_BWD_TPB(1, false, nullptr, nullptr);
         return hipGetLastError();
     }
+#undef BRUSH_RASTER_BWD_TPB
+#undef BRUSH_RASTER_BWD
     const bool wide = tiles >= kMinTilesForOneWave;
     const uint32_t units = tiles * (wide ? 1u : 2u);
     const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
