@@ -20,7 +20,10 @@
 //     tiles before it and of all tiles itself (T coalesced 1-KiB row reads, T = the ACTUAL tile count of
 //     *d_n, ~26-64 at the headline scene) instead of waiting for a scan launch: at 100 k - 400 k keys a
 //     pass is bound by kernel boundaries (~4 us each), not by bytes.
-//   * otherwise 3 launches per pass with counts laid out [digit][tile] and the scan kernel.
+//   * otherwise 3 launches per pass with counts laid out [digit][tile] and the scan kernel, fixed 8192-key tiles and
+//     512-thread scatter workgroups whose 76 KiB of LDS let two of them share a CU (one's loads and stores overlap the
+//     other's ranking): the 18 M-key tile sort of the 4K / 20 M-splat frame 326 -> 246 us (37 % of the HBM peak);
+//     256-thread / 4096-key workgroups (four per CU) measured slower (278 us: shorter digit runs, twice the tiles).
 // The element count stays on the device (*d_n): grids are sized for max_n and surplus blocks exit on
 // their first instruction.  Stability: tiles, wave chunks, rounds and lanes are all ranked in index order.
 // Traffic per pass: 4 B/key (upsweep) + 16 B/pair (downsweep).  Roofline: HBM at large n, kernel
@@ -39,6 +42,10 @@ constexpr uint32_t kSortTargetTiles = 128;
 constexpr uint32_t kRadix = 256;
 constexpr uint32_t kMaxTileKeys = kSortThreads * kSortMaxItems;  // 16384
 constexpr uint32_t kFusedMaxTiles = 512;
+// Sorts larger than that (3-launch shape): fixed 8192-key tiles, scattered by 512-thread workgroups of 16 keys per
+// lane whose LDS image (74 KiB) lets TWO of them share a CU, so one's loads and stores overlap the other's ranking.
+constexpr uint32_t kBigTileKeys = 8192;
+constexpr uint32_t kBigThreads = 512;
 
 // Keys per lane for a sort of n keys: smallest power of two K in [1,16] with n / (1024 K) <= 128.
 __host__ __device__ __forceinline__ uint32_t sort_items(uint32_t n) {
@@ -49,7 +56,11 @@ __host__ __device__ __forceinline__ uint32_t sort_items(uint32_t n) {
 // Upper bound of the tile count over every n <= max_n.
 inline uint32_t sort_max_tiles(uint32_t max_n) {
     const uint32_t big = (uint32_t)(((uint64_t)max_n + kMaxTileKeys - 1) / kMaxTileKeys);
+    if (big > kFusedMaxTiles) return (uint32_t)(((uint64_t)max_n + kBigTileKeys - 1) / kBigTileKeys);
     return big > kSortTargetTiles ? big : kSortTargetTiles;  // n <= 128 * 1024 * K selects K: never more than 128 tiles
+}
+inline bool sort_is_fused(uint32_t max_n) {
+    return (uint32_t)(((uint64_t)max_n + kMaxTileKeys - 1) / kMaxTileKeys) <= kFusedMaxTiles;
 }
 
 template <bool FUSED>
@@ -58,7 +69,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_upsweep(const uint32_t *_
                                                               uint32_t shift, uint32_t mask,
                                                               uint32_t *__restrict__ counts, uint32_t max_tiles) {
     const uint32_t n = min(*d_n, max_n);
-    const uint32_t items = sort_items(n);
+    const uint32_t items = FUSED ? sort_items(n) : kBigTileKeys / kSortThreads;
     const uint32_t tile_keys = kSortThreads * items;
     const uint32_t tile = blockIdx.x;
     if ((uint64_t)tile * tile_keys >= n) return;
@@ -89,8 +100,7 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ counts
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t carry_s;
     const uint32_t n = min(*d_n, max_n);
-    const uint32_t tile_keys = kSortThreads * sort_items(n);
-    const uint32_t num_tiles = (n + tile_keys - 1) / tile_keys;
+    const uint32_t num_tiles = (n + kBigTileKeys - 1) / kBigTileKeys;
     uint32_t *row = counts + (size_t)blockIdx.x * max_tiles;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -112,16 +122,20 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ counts
 
 // LDS of the downsweep: the tile's pairs reordered by digit (128 KiB at 16 keys per lane) + the per-wave
 // digit counters.  One 1024-thread workgroup per CU.
-struct DownLds {
-    uint32_t keys[kMaxTileKeys];
-    uint32_t vals[kMaxTileKeys];
-    uint32_t wave_hist[kSortWaves][kRadix];
+template <uint32_t TILE_KEYS, uint32_t WAVES, uint32_t PARTS>
+struct DownLdsT {
+    uint32_t keys[TILE_KEYS];
+    uint32_t vals[TILE_KEYS];
+    uint32_t wave_hist[WAVES][kRadix];
     uint32_t digit_base[kRadix];  // global position of the tile's first key of each digit
     uint32_t tile_start[kRadix];  // position inside the tile (after the reorder) of each digit's run
-    uint32_t part[4][kRadix];     // FUSED: partial column sums (keys of earlier tiles), 4 tile-quarters
-    uint32_t part_all[4][kRadix]; // FUSED: partial column sums over all tiles
+    uint32_t part[PARTS][kRadix];     // FUSED: partial column sums (keys of earlier tiles), 4 tile-quarters
+    uint32_t part_all[PARTS][kRadix]; // FUSED: partial column sums over all tiles
     uint32_t wave_tot2[4][2];
 };
+using DownLds = DownLdsT<kMaxTileKeys, kSortWaves, 4>;
+using DownLdsBig = DownLdsT<kBigTileKeys, kBigThreads / kWave, 1>;
+static_assert(2 * sizeof(DownLdsBig) <= 160 * 1024, "two large-sort workgroups per CU");
 
 // Exclusive scans of two 256-entry arrays held by threads 0..255 (one value of each per thread) behind the same
 // two barriers; all 1024 threads must call.
@@ -141,20 +155,22 @@ __device__ __forceinline__ void block_excl_scan256_pair(uint32_t &a, uint32_t &b
     a = oa, b = ob;
 }
 
-template <bool FUSED, uint32_t ITEMS>
+template <bool FUSED, uint32_t ITEMS, uint32_t THREADS, typename LDS>
 __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys_in,
                                                const uint32_t *__restrict__ vals_in,
                                                uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                uint32_t n, uint32_t shift, uint32_t mask,
                                                const uint32_t *__restrict__ counts,
                                                const uint32_t *__restrict__ totals, uint32_t max_tiles,
-                                               DownLds &L) {
-    constexpr uint32_t kTileKeys = kSortThreads * ITEMS;
+                                               LDS &L) {
+    static_assert(!FUSED || THREADS == kSortThreads, "the fused table sums assume 4 quarters of 256 threads");
+    constexpr uint32_t kTileKeys = THREADS * ITEMS;
+    constexpr uint32_t kWaves = THREADS / kWave;
     constexpr bool kReorder = ITEMS > 2;  // small sorts: the scatter is a few hundred KB, not worth two barriers
     const uint32_t tile = blockIdx.x;
     const uint32_t wid = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
-    for (uint32_t i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&L.wave_hist[0][0])[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kWaves * kRadix; i += THREADS) (&L.wave_hist[0][0])[i] = 0;
 
     // Each wave owns a contiguous chunk of 64*ITEMS keys; round i covers keys chunk + i*64 + lane.
     // The loads are issued first so that they are in flight during the table sums below.
@@ -230,7 +246,7 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
     if (threadIdx.x < kRadix) {
         const uint32_t d = threadIdx.x;
 #pragma unroll
-        for (uint32_t w = 0; w < kSortWaves; w++) {
+        for (uint32_t w = 0; w < kWaves; w++) {
             const uint32_t t = L.wave_hist[w][d];
             L.wave_hist[w][d] = tile_cnt;
             tile_cnt += t;
@@ -278,7 +294,7 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
     const uint32_t tile_n = min(kTileKeys, n - tile_base);
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; i++) {
-        const uint32_t lp = i * kSortThreads + threadIdx.x;
+        const uint32_t lp = i * THREADS + threadIdx.x;
         if (lp < tile_n) {
             const uint32_t k = L.keys[lp];
             const uint32_t digit = (k >> shift) & mask;
@@ -300,8 +316,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
     if ((uint64_t)blockIdx.x * kSortThreads * items >= n) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     DownLds &L = *reinterpret_cast<DownLds *>(lds_raw);
-#define BRUSH_DOWN(K) \
-    downsweep_body<FUSED, K>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, counts, totals, max_tiles, L)
+#define BRUSH_DOWN(K)                                                                                             \
+    downsweep_body<FUSED, K, kSortThreads>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, counts, totals, \
+                                           max_tiles, L)
     switch (items) {  // block-uniform
         case 1: BRUSH_DOWN(1); break;
         case 2: BRUSH_DOWN(2); break;
@@ -310,6 +327,20 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
         default: BRUSH_DOWN(16); break;
     }
 #undef BRUSH_DOWN
+}
+
+// Large sorts: one 8192-key tile per 512-thread workgroup, two workgroups per CU.
+__global__ __launch_bounds__(kBigThreads) void k_sort_downsweep_big(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ d_n,
+    uint32_t max_n, uint32_t shift, uint32_t mask, const uint32_t *__restrict__ counts,
+    const uint32_t *__restrict__ totals, uint32_t max_tiles) {
+    const uint32_t n = min(*d_n, max_n);
+    if ((uint64_t)blockIdx.x * kBigTileKeys >= n) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    DownLdsBig &L = *reinterpret_cast<DownLdsBig *>(lds_raw);
+    downsweep_body<false, kBigTileKeys / kBigThreads, kBigThreads>(keys_in, vals_in, keys_out, vals_out, n, shift,
+                                                                   mask, counts, totals, max_tiles, L);
 }
 
 __global__ void k_sort_copy(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
@@ -346,8 +377,8 @@ hipError_t enable_big_lds() {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLds));
         if (e != hipSuccess) return e;
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLds));
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep_big),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLdsBig));
     }();
     return st;
 }
@@ -370,7 +401,7 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
     }
     const hipError_t lds = enable_big_lds();
     if (lds != hipSuccess) return lds;
-    const bool fused = w.max_tiles <= kFusedMaxTiles;
+    const bool fused = sort_is_fused(max_n);
     const uint32_t *src_k = keys_in, *src_v = vals_in;
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t shift = p * 8u;
@@ -388,7 +419,7 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
             hipLaunchKernelGGL(k_sort_upsweep<false>, dim3(w.max_tiles), dim3(kSortThreads), 0, s, src_k, d_n, max_n,
                                shift, mask, w.counts, w.max_tiles);
             hipLaunchKernelGGL(k_sort_scan, dim3(kRadix), dim3(256), 0, s, w.counts, d_n, max_n, w.max_tiles, w.totals);
-            hipLaunchKernelGGL(k_sort_downsweep<false>, dim3(w.max_tiles), dim3(kSortThreads), sizeof(DownLds), s,
+            hipLaunchKernelGGL(k_sort_downsweep_big, dim3(w.max_tiles), dim3(kBigThreads), sizeof(DownLdsBig), s,
                                src_k, src_v, dst_k, dst_v, d_n, max_n, shift, mask, w.counts, w.totals, w.max_tiles);
         }
         src_k = dst_k;
