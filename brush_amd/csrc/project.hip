@@ -44,7 +44,8 @@ constexpr uint32_t kCullBlock = kThreads * kCullPerThread;  // splats per cull w
 //     64-tile step per item), so a whole-screen splat is spread over many waves.
 // If the queue is full the lane falls back to walking its bbox inline (slow, still correct).
 // The hit masks are kept so that the emission pass never repeats the exact test.
-constexpr uint32_t kSmallArea = 16;
+constexpr uint32_t kSmallArea = 16;      // few visible splats (latency-bound launch): short inline walks
+constexpr uint32_t kSmallAreaMany = 64;  // many visible splats (throughput-bound): everything one hit mask can hold
 constexpr uint32_t kChunkTiles = 64;   // one 64-bit hit mask per queue item
 constexpr uint32_t kWalkGroupMax = 16;  // queue items a consumer wave takes at a time when the queue is long
 // Few items: small groups (more waves, shorter serial chains); many items: amortise the memory phase.
@@ -419,9 +420,10 @@ __global__ __launch_bounds__(kThreads) void k_compact(uint32_t n, const uint32_t
 __global__ __launch_bounds__(kThreads) void k_project_visible(
     ViewParams vp, const float4 *__restrict__ proj_global, const uint32_t *__restrict__ num_visible,
     uint32_t *__restrict__ global_from_compact, uint32_t *__restrict__ compact_from_global,
-    float *__restrict__ projected, uint32_t *__restrict__ tiles_hit, WalkQueue q) {
+    float *__restrict__ projected, uint32_t *__restrict__ tiles_hit, WalkQueue q, uint32_t small_switch) {
     const uint32_t V = *num_visible;
     const uint32_t n = vp.total_splats;
+    const uint32_t small_area = V > small_switch ? kSmallAreaMany : kSmallArea;
     // Tail of global_from_compact_gid (never written by the sort) := 0.
     for (uint32_t i = V + blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
         global_from_compact[i] = 0;
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
         // Queue slots are reserved with ONE atomicAdd per wave (wave scan of the chunk counts); a
         // per-lane atomic on the single counter serialises tens of thousands of requests.
         const uint32_t bbox_tiles = active ? (bb[2] - bb[0]) * (bb[3] - bb[1]) : 0u;
-        const uint32_t nchunks = bbox_tiles > kSmallArea ? (bbox_tiles + kChunkTiles - 1) / kChunkTiles : 0u;
+        const uint32_t nchunks = bbox_tiles > small_area ? (bbox_tiles + kChunkTiles - 1) / kChunkTiles : 0u;
         const uint32_t incl = wave_inclusive_scan(nchunks);
         const uint32_t wave_total = __shfl(incl, 63, 64);
         uint32_t wave_base = 0;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
             }
         }
         // small bboxes: flattened across the wave
-        const bool small = active && bbox_tiles <= kSmallArea;
+        const bool small = active && bbox_tiles <= small_area;
         uint32_t flat_cnt;
         uint64_t flat_mask;
         walk_flat(small ? bbox_tiles : 0u, bb, tt, xy, 0u, flat_cnt, flat_mask);
@@ -769,8 +771,12 @@ hipError_t launch_project_visible(const ViewParams &vp, const float *proj_global
                                   uint32_t *tiles_hit, const WalkWs &walk, hipStream_t s) {
     const WalkQueue q = make_queue(walk);
     const dim3 grid(stride_grid(vp.total_splats)), block(kThreads);
+    static const uint32_t small_switch = [] {  // visible-splat count above which bboxes up to 64 tiles are walked inline
+        const char *e = getenv("BRUSH_WALK_SWITCH");
+        return e ? (uint32_t)atoi(e) : (1u << 19);
+    }();
     hipLaunchKernelGGL(k_project_visible, grid, block, 0, s, vp, reinterpret_cast<const float4 *>(proj_global),
-                       num_visible, global_from_compact, compact_from_global, projected, tiles_hit, q);
+                       num_visible, global_from_compact, compact_from_global, projected, tiles_hit, q, small_switch);
     hipLaunchKernelGGL(k_walk_count, dim3(1024), dim3(kThreads), 0, s, vp, projected, q, tiles_hit);
     return hipGetLastError();
 }

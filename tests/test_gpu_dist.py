@@ -124,8 +124,10 @@ def test_record_exchange_two_ranks_one_gpu():
         assert steps[1]["regrown"] >= 1 and steps[2]["regrown"] == steps[1]["regrown"]  # ... once
         for s in steps:
             assert s["V"] > 1000 and s["gid_ok"]
-            assert s["rec_err"] <= 2e-6                            # one extra rounding in v_rgb = v_sh0 / Y0
-            assert s["err"] <= 2e-6 * s["scale"], (rank, s["step"], s["err"], s["scale"])
+            # the records and the dense gradients come from two backward calls whose float atomics land in different
+            # orders (+ one extra rounding in v_rgb = v_sh0 / Y0): a few ulp of the tensor's scale
+            assert s["rec_err"] <= 5e-6
+            assert s["err"] <= 5e-6 * s["scale"], (rank, s["step"], s["err"], s["scale"])
     # the reduced gradients are the same bits on both ranks, every step
     for a, b in zip(got[0][0], got[1][0]):
         assert np.array_equal(a["red"].view(np.uint32), b["red"].view(np.uint32)), a["step"]
