@@ -405,6 +405,68 @@ __device__ __forceinline__ void store_gradients_or_step(
     }
 }
 
+// ---- dense gradients (brush_render_backward): the zeros ------------------------------------------------------------
+// ~90 % of the splats are not visible from the view, so most of the 52 + 12C bytes per splat the backward writes are
+// zeros.  The lanes that own the addresses store them straight from registers: consecutive lanes, consecutive 16-byte
+// words of the wave's contiguous regions, the rows of visible splats skipped by their bit in the wave's visibility mask
+// `vis`; the visible splats' rows are written by the lanes that computed them (k_project_backward).  No LDS staging, no
+// transposes (the staged form spent 56 % of its LDS cycles in bank conflicts): 65 -> 49 us at 1 M splats.
+// The v_sh rows are whole cache lines (192 B at degree 3), so their zeros are streaming stores; the small arrays share
+// lines between neighbouring splats, visible or not, and use ordinary stores, which the L2 merges into full lines (a
+// streaming store of part of a line costs a whole line at the memory: 92 us).  For the same reason the visible rows are
+// written by the workgroup that owns their neighbours: a variant with separate workgroups walking the visible splats in
+// depth order wrote the same bytes 35 % slower at 21 M splats (1.73 vs 1.28 ms), the partial lines no longer meeting
+// in the L2.
+template <int DEG>
+__device__ __forceinline__ void zero_invisible_rows(uint32_t n, uint32_t g0, uint32_t lane, uint64_t vis,
+                                                    float *__restrict__ v_means, float *__restrict__ v_xy,
+                                                    float *__restrict__ v_scales, float *__restrict__ v_quats,
+                                                    float *__restrict__ v_sh, float *__restrict__ v_opac) {
+    constexpr uint32_t kRow = (DEG + 1) * (DEG + 1) * 3;  // floats per v_sh row
+    const uint32_t rows = min(kWave, n - g0);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float *sh = v_sh + (size_t)g0 * kRow;
+    if constexpr (kRow % 16 == 0) {  // rows of whole 64-byte lines
+        constexpr uint32_t kPerRow = kRow / 4;
+        const uint32_t total = rows * kPerRow;
+#pragma unroll
+        for (uint32_t it = 0; it < kPerRow; it++) {
+            const uint32_t q = it * kWave + lane;
+            if (q < total && !((vis >> (q / kPerRow)) & 1ull)) nt_store4(sh + (size_t)q * 4, z4);
+        }
+    } else {
+        const uint32_t total = rows * kRow;
+#pragma unroll
+        for (uint32_t it = 0; it < kRow; it++) {
+            const uint32_t f = it * kWave + lane;
+            if (f < total && !((vis >> (f / kRow)) & 1ull)) sh[f] = 0.0f;
+        }
+    }
+    if (lane < rows && !((vis >> lane) & 1ull)) {
+        const size_t g = (size_t)g0 + lane;
+        if (v_xy) reinterpret_cast<float2 *>(v_xy)[g] = make_float2(0.f, 0.f);
+        reinterpret_cast<float4 *>(v_quats)[g] = z4;
+        v_opac[g] = 0.0f;
+    }
+    // v_means / v_scales: 3 floats per splat; 16-byte word `lane` of the wave's region covers floats 4 lane .. 4 lane + 3,
+    // i.e. rows (4 lane) / 3 and (4 lane + 3) / 3
+    if (lane < 48u) {
+        const uint32_t f0 = lane * 4u, ra = f0 / 3u, rb = (f0 + 3u) / 3u;
+        const bool a_vis = (vis >> ra) & 1ull, b_vis = (vis >> rb) & 1ull;
+        float *m = v_means + (size_t)g0 * 3 + f0, *sc = v_scales + (size_t)g0 * 3 + f0;
+        if (rb < rows && !a_vis && !b_vis) {
+            *reinterpret_cast<float4 *>(m) = z4;
+            *reinterpret_cast<float4 *>(sc) = z4;
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) {
+                const uint32_t r = (f0 + i) / 3u;
+                if (r < rows && !((vis >> r) & 1ull)) m[i] = 0.0f, sc[i] = 0.0f;
+            }
+        }
+    }
+}
+
 // ADAM: instead of storing the dense parameter gradients, every element goes straight through the
 // optimizer update of its parameter (brush_render_backward_adam): the 52+12C bytes per splat of
 // gradients are never written to nor re-read from HBM.  v_xy is still stored (refinement statistics).
@@ -440,8 +502,9 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     __shared__ uint16_t vis_list[kThreads];
     static_assert(kThreads * kRes <= (kThreads / kWave) * kStageFloats, "result rows must fit the staging buffer");
     float *res = &stage_all[0][0];
+    const uint64_t own_vis = __ballot(c_own != kInvalid);
     {
-        const uint64_t bal = __ballot(c_own != kInvalid);
+        const uint64_t bal = own_vis;
         if (lane == 0) vis_cnt[wv] = __popcll(bal);
         __syncthreads();
         uint32_t pos = __popcll(bal & lanemask_lt());
@@ -453,6 +516,8 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     const uint32_t li = threadIdx.x < nvis ? vis_list[threadIdx.x] : 0u;
     const uint32_t g = blockIdx.x * kThreads + li;
     const uint32_t c = threadIdx.x < nvis ? compact_from_global[g] : kInvalid;
+    // Dense gradients: the zeros of the invisible splats go out first, so the stores are in flight during the VJP
+    if (!ADAM && g0 < n) zero_invisible_rows<DEG>(n, g0, lane, own_vis, v_means, v_xy, v_scales, v_quats, v_sh, v_opac);
 
     float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_quat[4] = {0.f, 0.f, 0.f, 0.f};
     float o_xy[2] = {0.f, 0.f}, o_opac = 0.f;
@@ -489,15 +554,37 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
         // ---- ProjectBackwards (project_backwards.wgsl:83-226)
         splat_projection_vjp(vp, mean, scale, quat, vxy, vconic, o_mean, o_scale, o_quat);
 
-        float *r = res + li * kRes;  // hand the results to the lane that owns splat `li`
-        r[0] = o_mean[0], r[1] = o_mean[1], r[2] = o_mean[2];
-        r[3] = o_scale[0], r[4] = o_scale[1], r[5] = o_scale[2];
-        r[6] = o_quat[0], r[7] = o_quat[1], r[8] = o_quat[2], r[9] = o_quat[3];
-        r[10] = o_opac, r[11] = o_xy[0], r[12] = o_xy[1];
-        r[13] = vcol[0], r[14] = vcol[1], r[15] = vcol[2];
+        if (!ADAM) {  // dense gradients: the computing lane writes the visible splat's rows itself (ordinary stores)
+            const size_t gg = g;
+            if (v_xy) reinterpret_cast<float2 *>(v_xy)[gg] = make_float2(o_xy[0], o_xy[1]);
+            reinterpret_cast<float4 *>(v_quats)[gg] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
+            v_opac[gg] = o_opac;
 #pragma unroll
-        for (uint32_t k = 0; k < ncoef; k++) r[16 + k] = Y[k];
+            for (int k = 0; k < 3; k++) v_means[gg * 3 + k] = o_mean[k], v_scales[gg * 3 + k] = o_scale[k];
+            float *row = v_sh + gg * kRow;  // v_sh row = Y[k] * v_rgb (gather_grads.wgsl:186-222)
+            if constexpr (kRow % 4 == 0) {
+#pragma unroll
+                for (uint32_t j = 0; j < kRow / 4; j++)
+                    reinterpret_cast<float4 *>(row)[j] =
+                        make_float4(Y[(4 * j) / 3] * vcol[(4 * j) % 3], Y[(4 * j + 1) / 3] * vcol[(4 * j + 1) % 3],
+                                    Y[(4 * j + 2) / 3] * vcol[(4 * j + 2) % 3], Y[(4 * j + 3) / 3] * vcol[(4 * j + 3) % 3]);
+            } else {
+#pragma unroll
+                for (uint32_t e = 0; e < kRow; e++) row[e] = Y[e / 3] * vcol[e % 3];
+            }
+        }
+        if (ADAM) {
+            float *r = res + li * kRes;  // hand the results to the lane that owns splat `li`
+            r[0] = o_mean[0], r[1] = o_mean[1], r[2] = o_mean[2];
+            r[3] = o_scale[0], r[4] = o_scale[1], r[5] = o_scale[2];
+            r[6] = o_quat[0], r[7] = o_quat[1], r[8] = o_quat[2], r[9] = o_quat[3];
+            r[10] = o_opac, r[11] = o_xy[0], r[12] = o_xy[1];
+            r[13] = vcol[0], r[14] = vcol[1], r[15] = vcol[2];
+#pragma unroll
+            for (uint32_t k = 0; k < ncoef; k++) r[16 + k] = Y[k];
+        }
     }
+    if (!ADAM) return;  // nothing left to exchange: no barrier below is reached by any wave of the block
     __syncthreads();
     {
         const float *r = res + threadIdx.x * kRes;
@@ -650,8 +737,9 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
                                    const uint32_t *compact_from_global, const float *v_compact, float *v_means,
                                    float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
                                    const AdamFuse *adam, const DetSumsArgs &dargs, hipStream_t s) {
-    if (vp.total_splats == 0) return hipSuccess;
-    const dim3 grid(ceil_div(vp.total_splats, kThreads)), block(kThreads);
+    const uint32_t n = vp.total_splats;
+    if (n == 0) return hipSuccess;
+    const dim3 grid(ceil_div(n, kThreads)), block(kThreads);
     AdamFuse af{};
     if (adam) af = *adam;
     const DetSums det{dargs.cum_tiles_hit, dargs.num_intersections, dargs.partials, dargs.cap};
