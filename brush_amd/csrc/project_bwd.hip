@@ -185,7 +185,7 @@ __device__ __forceinline__ void load_compact_sums(const float *__restrict__ v_co
         return;
     }
     for (uint32_t k = k0; k <= k1; k++) {  // chunk order
-        const float4 *p = reinterpret_cast<const float4 *>(det.partials) + ((size_t)k * 2 + (k == k0 ? 1 : 0)) * 3;
+        const float4 *p = reinterpret_cast<const float4 *>(det.partials) + ((size_t)k * 2 + (k == k0 ? 1 : 0)) * kCompactVec;
         const float4 a = p[0], b = p[1], d = p[2];
         r0.x += a.x, r0.y += a.y, r0.z += a.z, r0.w += a.w;
         r1.x += b.x, r1.y += b.y, r1.z += b.z, r1.w += b.w;
@@ -204,13 +204,13 @@ __global__ __launch_bounds__(kThreads) void k_sum_isect_rows(const float4 *__res
     for (uint32_t k = blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave; (uint64_t)k * kWave < I; k += waves) {
         const uint32_t base = k * kWave, u = base + lane;
         const bool valid = u < I;
-        float v[kCompactStride];
+        float v[12];
         uint32_t c = 0, first = lane, last = lane;
         bool starts_here = true, ends_here = true;
 #pragma unroll
-        for (uint32_t i = 0; i < kCompactStride; i++) v[i] = 0.f;
+        for (uint32_t i = 0; i < 12; i++) v[i] = 0.f;
         if (valid) {
-            const float4 a = rows[(size_t)u * 3], b = rows[(size_t)u * 3 + 1], d = rows[(size_t)u * 3 + 2];
+            const float4 a = rows[(size_t)u * kCompactVec], b = rows[(size_t)u * kCompactVec + 1], d = rows[(size_t)u * kCompactVec + 2];
             v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w, v[8] = d.x;
             c = __float_as_uint(d.y);
             const uint32_t u0 = c ? min(cum_tiles_hit[c - 1], I) : 0u, u1 = min(cum_tiles_hit[c], I);
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(kThreads) void k_sum_isect_rows(const float4 *__res
             }
         }
         if (valid && lane == last) {
-            float4 *dst = (starts_here && ends_here) ? v_compact + (size_t)c * 3
-                                                     : partials + ((size_t)k * 2 + (starts_here ? 1 : 0)) * 3;
+            float4 *dst = (starts_here && ends_here) ? v_compact + (size_t)c * kCompactVec
+                                                     : partials + ((size_t)k * 2 + (starts_here ? 1 : 0)) * kCompactVec;
             dst[0] = make_float4(v[0], v[1], v[2], v[3]);
             dst[1] = make_float4(v[4], v[5], v[6], v[7]);
             dst[2] = make_float4(v[8], 0.f, 0.f, 0.f);

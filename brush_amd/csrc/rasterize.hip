@@ -591,8 +591,8 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
 // which are the v_xy factors of rasterize_backwards.wgsl:260-263 as well.
 //
 // DET (deterministic mode, NQ = 4 only: one wave per tile, so every intersection has exactly one producer):
-// instead of adding to the splat's compact row with float atomics, the wave STORES one 48-byte row per
-// intersection, [9 sums | compact gid | 0 | 0], at the position the intersection had before the tile sort
+// instead of adding to the splat's compact row with float atomics, the wave STORES one 64-byte row per
+// intersection, [9 sums | compact gid | 0 ...], at the position the intersection had before the tile sort
 // (`unsorted_pos`, grouped by splat); intersections it does not walk get zero rows.  k_sum_isect_rows then adds a
 // splat's rows in that fixed order.
 template <uint32_t NQ, bool DET, uint32_t TPB>
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
     auto zero_rows = [&](uint32_t lo, uint32_t hi) {
         for (uint32_t i = lo + lane; i < hi; i += kWave) {
             float4 *r = reinterpret_cast<float4 *>(rows + (size_t)unsorted_pos[i] * kCompactStride);
-            r[0] = r[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            r[0] = r[1] = r[3] = make_float4(0.f, 0.f, 0.f, 0.f);  // the whole 64-byte row
             r[2] = make_float4(0.f, __uint_as_float(gid_from_isect[i]), 0.f, 0.f);
         }
     };

@@ -151,7 +151,7 @@ int brush_render_forward_rgba8(const BrushUniforms *uniforms, const float *means
 int brush_deterministic(void);
 int brush_bwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
                              size_t *bytes);
-/* As above with the intersection capacity explicit (the deterministic mode keeps 48 bytes per intersection);
+/* As above with the intersection capacity explicit (the deterministic mode keeps 64 bytes per intersection);
  * brush_bwd_workspace_size assumes brush_default_max_intersects(n, w, h). */
 int brush_bwd_workspace_size_ex(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree, uint32_t max_intersects,
                                 size_t *bytes);
