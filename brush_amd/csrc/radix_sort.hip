@@ -190,16 +190,17 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
         const uint32_t num_tiles = (n + kTileKeys - 1) / kTileKeys;
         const uint32_t d = threadIdx.x & (kRadix - 1), qt = threadIdx.x / kRadix;
         uint32_t below = 0, all = 0;
-        // 8 independent row loads in flight per thread: the loop is latency-, not bandwidth-bound
-        for (uint32_t t0 = qt; t0 < num_tiles; t0 += 32) {
-            uint32_t c[8];
+        // kTableLoads independent row loads in flight per thread: the loop is latency-, not bandwidth-bound
+        constexpr uint32_t kTableLoads = 16;
+        for (uint32_t t0 = qt; t0 < num_tiles; t0 += 4 * kTableLoads) {
+            uint32_t c[kTableLoads];
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) {
+            for (uint32_t j = 0; j < kTableLoads; j++) {
                 const uint32_t t = t0 + 4 * j;
                 c[j] = t < num_tiles ? counts[(size_t)t * kRadix + d] : 0u;
             }
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) {
+            for (uint32_t j = 0; j < kTableLoads; j++) {
                 all += c[j];
                 below += (t0 + 4 * j) < tile ? c[j] : 0u;
             }
