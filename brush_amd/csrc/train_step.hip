@@ -4,8 +4,8 @@
 // one or two HBM-streaming kernels.
 //
 //   k_ssim_forward / k_ssim_backward : loss = L1*(1-w) - SSIM*w (train.rs:243-268) with the SSIM of
-//       ssim.rs:42-101 (11x11 Gaussian window sigma 1.5, zero padding div_ceil(11,2) = 6, so the SSIM
-//       map is (h+2)x(w+2); variances clamped at 0) and d loss / d pred.  The window is outer(g, g), so
+//       ssim.rs:42-101 (Gaussian window sigma 1.5, 11x11 by default, zero padding div_ceil(window,2), so the SSIM
+//       map of an odd window is (h+2)x(w+2); variances clamped at 0) and d loss / d pred.  The window is outer(g, g), so
 //       every blur is two 1-D passes (same linear operator, ssim.rs:17-32 notes it as a TODO): horizontal
 //       through a per-wave LDS row buffer, vertical over a register ring while the wave marches down.
 //   k_adam : Adam with the reference's five learning rates and the SH-rest lerp (train.rs:318-359) over
@@ -20,15 +20,22 @@
 namespace brush {
 namespace {
 
-constexpr int kWin = 11;        // ssim window (TrainConfig::ssim_window_size default, train.rs:63)
-constexpr int kPad = 6;         // div_ceil(11, 2), ssim.rs:49
-constexpr int kOutCols = 54;    // columns a wave produces: 64 lanes minus the 10-column halo
-constexpr int kSegRows = 34;    // rows a block produces: 34 + 10 halo = 4 * 11 marched rows
-constexpr int kRowBuf = 80;     // floats per LDS row buffer (lane + 10 taps < 74)
+// The SSIM window: TrainConfig::ssim_window_size (train.rs:63, default 11); odd sizes 3..15 are compiled.  For an odd
+// window 2m+1 the zero padding is div_ceil(window, 2) = m+1 (ssim.rs:49), so the SSIM map is (h+2) x (w+2) whatever
+// the size.
+constexpr int kMaxWin = 15;
+template <int WIN>
+struct Geo {
+    static constexpr int kPad = (WIN + 1) / 2;      // div_ceil(WIN, 2)
+    static constexpr int kOutCols = 64 - (WIN - 1);  // columns a wave produces: 64 lanes minus the halo
+    static constexpr int kSegRows = 3 * WIN + 1;     // rows a block produces: + (WIN - 1) halo = 4 * WIN marched rows
+    static constexpr int kOff = WIN - 1 - kPad;
+};
+constexpr int kRowBuf = 80;     // floats per LDS row buffer (lane + kMaxWin - 1 taps < 80)
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 struct Window {
-    float g[kWin];
+    float g[kMaxWin];
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -65,22 +72,24 @@ __device__ __forceinline__ void wave_lds_sync() {
 // three derivative maps (wrt blur(a), blur(a*a), blur(a*b); a = pred, b = gt) scaled by `coef`, and
 // per-wave partial sums of the SSIM map and of |pred - gt| (each input pixel owned by the wave
 // holding map position (iy+1, ix+1)).
+template <int WIN>
 __global__ __launch_bounds__(192) void k_ssim_forward(const float *__restrict__ pred, const float *__restrict__ gt,
                                                       uint32_t gt_channels, uint32_t w, uint32_t h, Window win,
                                                       float coef, float *__restrict__ dmaps,
                                                       float *__restrict__ partials) {
+    using G = Geo<WIN>;
     __shared__ float rows[3][2][kRowBuf];
     const int ch = threadIdx.x / kWave, l = lane_id();
     float *ra = rows[ch][0], *rb = rows[ch][1];
     const int W2 = w + 2, H2 = h + 2;
-    const int x0 = blockIdx.x * kOutCols, oy0 = blockIdx.y * kSegRows;
-    const int ix = x0 - kPad + l;
+    const int x0 = blockIdx.x * G::kOutCols, oy0 = blockIdx.y * G::kSegRows;
+    const int ix = x0 - G::kPad + l;
     const bool col_ok = ix >= 0 && ix < (int)w;
     const int ox = x0 + l;
-    const bool out_col = l < kOutCols && ox < W2;
-    const bool own_col = l >= kPad - 1 && l < kPad - 1 + kOutCols;
+    const bool out_col = l < G::kOutCols && ox < W2;
+    const bool own_col = l >= G::kPad - 1 && l < G::kPad - 1 + G::kOutCols;
     const size_t plane = (size_t)W2 * H2;
-    float hq[kWin][5];
+    float hq[WIN][5];
     float msum = 0.0f, l1 = 0.0f;
     // marched row r -> (a, b, alpha pair) of the lane's column, zero outside the image.  Loads are
     // unconditional (clamped address + select) and issued three rows ahead of their use, so the
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(192) void k_ssim_forward(const float *__restrict__ 
         float a, b, pa, ga;
     };
     auto fetch = [&](int r) {
-        const int iy = oy0 - kPad + r;
+        const int iy = oy0 - G::kPad + r;
         const bool ok = col_ok && iy >= 0 && iy < (int)h;
         const size_t px = (size_t)min(max(iy, 0), (int)h - 1) * w + ixc;
         Row v;
@@ -104,31 +113,31 @@ __global__ __launch_bounds__(192) void k_ssim_forward(const float *__restrict__ 
         return v;
     };
     Row c0 = fetch(0), c1 = fetch(1), c2 = fetch(2);
-    for (int r0 = 0; r0 < kSegRows + kWin - 1; r0 += kWin) {
+    for (int r0 = 0; r0 < G::kSegRows + WIN - 1; r0 += WIN) {
 #pragma unroll
-        for (int j = 0; j < kWin; j++) {
+        for (int j = 0; j < WIN; j++) {
             const int r = r0 + j;
             ra[l] = c0.a, rb[l] = c0.b;
-            if (own_col && r >= kPad - 1 && r < kPad - 1 + kSegRows) l1 += fabsf(c0.a - c0.b) + fabsf(c0.pa - c0.ga);
+            if (own_col && r >= G::kPad - 1 && r < G::kPad - 1 + G::kSegRows) l1 += fabsf(c0.a - c0.b) + fabsf(c0.pa - c0.ga);
             c0 = c1, c1 = c2;
             c2 = fetch(r + 3);
             wave_lds_sync();
             float sa = 0.f, sb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
 #pragma unroll
-            for (int k = 0; k < kWin; k++) {
+            for (int k = 0; k < WIN; k++) {
                 const float av = ra[l + k], bv = rb[l + k];
                 const float ga = win.g[k] * av, gb = win.g[k] * bv;
                 sa += ga, sb += gb, saa += ga * av, sbb += gb * bv, sab += ga * bv;
             }
             wave_lds_sync();
             hq[j][0] = sa, hq[j][1] = sb, hq[j][2] = saa, hq[j][3] = sbb, hq[j][4] = sab;
-            const int oy = oy0 + r - (kWin - 1);
-            if (r >= kWin - 1 && oy < H2) {  // ring slot of marched row r - 10 + k is (j + 1 + k) % 11
+            const int oy = oy0 + r - (WIN - 1);
+            if (r >= WIN - 1 && oy < H2) {  // ring slot of marched row r - (WIN - 1) + k is (j + 1 + k) % WIN
                 float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < kWin; k++) {
+                for (int k = 0; k < WIN; k++) {
 #pragma unroll
-                    for (int q = 0; q < 5; q++) v[q] += win.g[k] * hq[(j + 1 + k) % kWin][q];
+                    for (int q = 0; q < 5; q++) v[q] += win.g[k] * hq[(j + 1 + k) % WIN][q];
                 }
                 if (out_col) {
                     const float mx = v[0], my = v[1];
@@ -156,9 +165,10 @@ __global__ __launch_bounds__(192) void k_ssim_forward(const float *__restrict__ 
     if (l == 0) partials[wv] = msum, partials[nwave + wv] = l1;
 }
 
-// Image position (py, px): T[X](p) = sum_j g[j] X[p - 4 + j] per axis (the transposed blur; g is
+// Image position (py, px): T[X](p) = sum_j g[j] X[p - kOff + j] per axis (the transposed blur; g is
 // symmetric) of the three derivative maps, combined with the L1 term into d loss / d pred.  Wave 0
 // of block (0,0) also reduces the partial sums into the loss value.
+template <int WIN>
 __global__ __launch_bounds__(192) void k_ssim_backward(const float *__restrict__ pred, const float *__restrict__ gt,
                                                        uint32_t gt_channels, uint32_t w, uint32_t h, Window win,
                                                        const float *__restrict__ dmaps, float l1_coef,
@@ -166,31 +176,31 @@ __global__ __launch_bounds__(192) void k_ssim_backward(const float *__restrict__
                                                        uint32_t nwave_fwd, float l1_weight, float ssim_weight,
                                                        float inv_l1_count, float inv_ssim_count,
                                                        float *__restrict__ loss) {
+    using G = Geo<WIN>;
     __shared__ float rows[3][3][kRowBuf];
     const int ch = threadIdx.x / kWave, l = lane_id();
     const int W2 = w + 2, H2 = h + 2;
-    const int px0 = blockIdx.x * kOutCols, py0 = blockIdx.y * kSegRows;
-    constexpr int kOff = kWin - 1 - kPad;  // 4
-    const int ox = px0 - kOff + l;
+    const int px0 = blockIdx.x * G::kOutCols, py0 = blockIdx.y * G::kSegRows;
+    const int ox = px0 - G::kOff + l;
     const bool col_ok = ox >= 0 && ox < W2;
     const int px = px0 + l;
-    const bool out_col = l < kOutCols && px < (int)w;
+    const bool out_col = l < G::kOutCols && px < (int)w;
     const size_t plane = (size_t)W2 * H2;
     const float *d0 = dmaps + (0 * 3 + ch) * plane, *d1 = dmaps + (1 * 3 + ch) * plane, *d2 = dmaps + (2 * 3 + ch) * plane;
     auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };
-    float hq[kWin][3];
+    float hq[WIN][3];
     // marched row r: the three map values of the lane's column and (a, b, alpha pair) of the pixel the
-    // iteration will emit (row py0 + r - 10); unconditional loads three rows ahead, as in the forward.
+    // iteration will emit (row py0 + r - (WIN - 1)); unconditional loads three rows ahead, as in the forward.
     const bool alpha_on = gt_channels == 4;
     const int oxc = min(max(ox, 0), W2 - 1), pxc = min(px, (int)w - 1);
     struct Row {
         float x0, x1, x2, a, b, pa, ga;
     };
     auto fetch = [&](int r) {
-        const int oy = py0 - kOff + r;
+        const int oy = py0 - G::kOff + r;
         const bool ok = col_ok && oy >= 0 && oy < H2;
         const size_t o = (size_t)min(max(oy, 0), H2 - 1) * W2 + oxc;
-        const size_t p = (size_t)min(max(py0 + r - (kWin - 1), 0), (int)h - 1) * w + pxc;
+        const size_t p = (size_t)min(max(py0 + r - (WIN - 1), 0), (int)h - 1) * w + pxc;
         Row v;
         v.x0 = d0[o], v.x1 = d1[o], v.x2 = d2[o];
         v.a = pred[p * 4 + ch], v.b = gt[p * gt_channels + ch];
@@ -199,9 +209,9 @@ __global__ __launch_bounds__(192) void k_ssim_backward(const float *__restrict__
         return v;
     };
     Row c0 = fetch(0), c1 = fetch(1), c2 = fetch(2);
-    for (int r0 = 0; r0 < kSegRows + kWin - 1; r0 += kWin) {
+    for (int r0 = 0; r0 < G::kSegRows + WIN - 1; r0 += WIN) {
 #pragma unroll
-        for (int j = 0; j < kWin; j++) {
+        for (int j = 0; j < WIN; j++) {
             const int r = r0 + j;
             rows[ch][0][l] = c0.x0, rows[ch][1][l] = c0.x1, rows[ch][2][l] = c0.x2;
             const float a = c0.a, b = c0.b, pa = c0.pa, ga = c0.ga;
@@ -210,20 +220,20 @@ __global__ __launch_bounds__(192) void k_ssim_backward(const float *__restrict__
             wave_lds_sync();
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < kWin; k++) {
+            for (int k = 0; k < WIN; k++) {
                 s0 += win.g[k] * rows[ch][0][l + k];
                 s1 += win.g[k] * rows[ch][1][l + k];
                 s2 += win.g[k] * rows[ch][2][l + k];
             }
             wave_lds_sync();
             hq[j][0] = s0, hq[j][1] = s1, hq[j][2] = s2;
-            const int py = py0 + r - (kWin - 1);
-            if (r >= kWin - 1 && py < (int)h && out_col) {
+            const int py = py0 + r - (WIN - 1);
+            if (r >= WIN - 1 && py < (int)h && out_col) {
                 float t[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < kWin; k++) {
+                for (int k = 0; k < WIN; k++) {
 #pragma unroll
-                    for (int q = 0; q < 3; q++) t[q] += win.g[k] * hq[(j + 1 + k) % kWin][q];
+                    for (int q = 0; q < 3; q++) t[q] += win.g[k] * hq[(j + 1 + k) % WIN][q];
                 }
                 const size_t p = (size_t)py * w + px;
                 v_pred[p * 4 + ch] = t[0] + 2.0f * a * t[1] + b * t[2] + l1_coef * sgn(a - b);
@@ -380,20 +390,25 @@ __global__ __launch_bounds__(256) void k_refine_stats(const uint32_t *__restrict
     }
 }
 
-Window make_window() {
+Window make_window(int n) {
     Window win;
     float sum = 0.0f;
-    for (int i = 0; i < kWin; i++) {
-        const float d = (float)i - (float)(kWin / 2);
+    for (int i = 0; i < kMaxWin; i++) win.g[i] = 0.0f;
+    for (int i = 0; i < n; i++) {
+        const float d = (float)i - (float)(n / 2);
         win.g[i] = expf(-(d * d) / (2.0f * 1.5f * 1.5f));  // ssim.rs:7-14
         sum += win.g[i];
     }
-    for (int i = 0; i < kWin; i++) win.g[i] /= sum;
+    for (int i = 0; i < n; i++) win.g[i] /= sum;
     return win;
 }
 
-inline uint32_t loss_blocks_x(uint32_t w) { return ceil_div(w + 2, (uint32_t)kOutCols); }
-inline uint32_t loss_blocks_y(uint32_t h) { return ceil_div(h + 2, (uint32_t)kSegRows); }
+// Upper bound of the forward's workgroup count over the supported windows (the partial-sum buffer is sized without
+// knowing the window): the narrowest column strip (window 15) times the shortest row segment (window 3).
+inline uint32_t loss_blocks_max(uint32_t w, uint32_t h) {
+    return ceil_div(w + 2, (uint32_t)Geo<kMaxWin>::kOutCols) * ceil_div(h + 2, (uint32_t)Geo<3>::kSegRows);
+}
+inline bool window_ok(uint32_t n) { return n >= 3 && n <= (uint32_t)kMaxWin && (n & 1u); }
 constexpr uint32_t kL1Blocks = 1024;
 
 }  // namespace
@@ -404,7 +419,7 @@ using namespace brush;
 extern "C" int brush_loss_workspace_size(uint32_t w, uint32_t h, size_t *bytes) {
     if (!bytes || w == 0 || h == 0) return BRUSH_ERR_INVALID_ARG;
     const size_t plane = (size_t)(w + 2) * (h + 2);
-    const size_t nblk = std::max<size_t>((size_t)loss_blocks_x(w) * loss_blocks_y(h) * 3, kL1Blocks);
+    const size_t nblk = std::max<size_t>((size_t)loss_blocks_max(w, h) * 3, kL1Blocks);
     *bytes = align_up(9 * plane * sizeof(float), 256) + align_up(2 * nblk * sizeof(float), 256);
     return BRUSH_OK;
 }
@@ -414,7 +429,7 @@ extern "C" int brush_l1_ssim_loss(const float *pred, const float *gt, uint32_t w
                                   float *v_pred, void *workspace, size_t workspace_bytes, brush_stream_t stream) {
     if (!pred || !gt || !loss || !v_pred || !workspace || w == 0 || h == 0) return BRUSH_ERR_INVALID_ARG;
     if (gt_channels != 3 && gt_channels != 4) return BRUSH_ERR_INVALID_ARG;
-    if (ssim_weight > 0.0f && ssim_window != (uint32_t)kWin) return BRUSH_ERR_INVALID_ARG;
+    if (ssim_weight > 0.0f && !window_ok(ssim_window)) return BRUSH_ERR_INVALID_ARG;  // odd sizes 3..15
     size_t need = 0;
     brush_loss_workspace_size(w, h, &need);
     if (workspace_bytes < need) return BRUSH_ERR_WORKSPACE_SMALL;
@@ -433,14 +448,29 @@ extern "C" int brush_l1_ssim_loss(const float *pred, const float *gt, uint32_t w
         BRUSH_HIP_CHECK(hipGetLastError());
         return BRUSH_OK;
     }
-    const Window win = make_window();
+    const Window win = make_window((int)ssim_window);
     const float inv_ssim = 1.0f / (3.0f * (float)plane);
-    const dim3 gf(loss_blocks_x(w), loss_blocks_y(h)), gb(ceil_div(w, (uint32_t)kOutCols), ceil_div(h, (uint32_t)kSegRows));
-    hipLaunchKernelGGL(k_ssim_forward, gf, dim3(192), 0, s, pred, gt, gt_channels, w, h, win,
-                       -ssim_weight * inv_ssim * grad_scale, dmaps, partials);
-    hipLaunchKernelGGL(k_ssim_backward, gb, dim3(192), 0, s, pred, gt, gt_channels, w, h, win, dmaps,
-                       (1.0f - ssim_weight) * inv_l1 * grad_scale, v_pred, partials, gf.x * gf.y * 3, 1.0f - ssim_weight,
-                       ssim_weight, inv_l1, inv_ssim, loss);
+#define BRUSH_SSIM(W)                                                                                                \
+    do {                                                                                                             \
+        using G = Geo<W>;                                                                                            \
+        const dim3 gf(ceil_div(w + 2, (uint32_t)G::kOutCols), ceil_div(h + 2, (uint32_t)G::kSegRows));               \
+        const dim3 gb(ceil_div(w, (uint32_t)G::kOutCols), ceil_div(h, (uint32_t)G::kSegRows));                       \
+        hipLaunchKernelGGL(k_ssim_forward<W>, gf, dim3(192), 0, s, pred, gt, gt_channels, w, h, win,                 \
+                           -ssim_weight * inv_ssim * grad_scale, dmaps, partials);                                   \
+        hipLaunchKernelGGL(k_ssim_backward<W>, gb, dim3(192), 0, s, pred, gt, gt_channels, w, h, win, dmaps,         \
+                           (1.0f - ssim_weight) * inv_l1 * grad_scale, v_pred, partials, gf.x * gf.y * 3,            \
+                           1.0f - ssim_weight, ssim_weight, inv_l1, inv_ssim, loss);                                 \
+    } while (0)
+    switch (ssim_window) {
+        case 3: BRUSH_SSIM(3); break;
+        case 5: BRUSH_SSIM(5); break;
+        case 7: BRUSH_SSIM(7); break;
+        case 9: BRUSH_SSIM(9); break;
+        case 11: BRUSH_SSIM(11); break;
+        case 13: BRUSH_SSIM(13); break;
+        default: BRUSH_SSIM(15); break;
+    }
+#undef BRUSH_SSIM
     BRUSH_HIP_CHECK(hipGetLastError());
     return BRUSH_OK;
 }

@@ -203,10 +203,11 @@ int brush_reduce_view_records(const float *records, uint32_t num_views, uint32_t
  * HIP equivalents, so the metric's train iters/s is not bounded by caller-side launches. */
 
 /* loss = mean|pred_cmp - gt| * (1 - ssim_weight) - SSIM(pred_rgb, gt_rgb) * ssim_weight when
- * ssim_weight > 0, else the plain L1 mean (train.rs:243-268); SSIM as ssim.rs:42-101 (window 11,
- * sigma 1.5, zero padding 6 so the SSIM map is (h+2)x(w+2), variances clamped at 0).
+ * ssim_weight > 0, else the plain L1 mean (train.rs:243-268); SSIM as ssim.rs:42-101 (Gaussian
+ * window, sigma 1.5, zero padding div_ceil(window, 2) so the SSIM map is (h+2)x(w+2), variances clamped at 0).
  * pred: [h,w,4]; gt: [h,w,gt_channels], gt_channels 3 or 4 (4 compares alpha too, train.rs:248-252).
- * Writes loss[0] (device) and v_pred [h,w,4] = grad_scale * d loss / d pred.  ssim_window must be 11. */
+ * Writes loss[0] (device) and v_pred [h,w,4] = grad_scale * d loss / d pred.  ssim_window: odd sizes 3..15
+ * (TrainConfig::ssim_window_size, train.rs:63, default 11); anything else returns BRUSH_ERR_INVALID_ARG. */
 int brush_loss_workspace_size(uint32_t w, uint32_t h, size_t *bytes);
 int brush_l1_ssim_loss(const float *pred, const float *gt, uint32_t w, uint32_t h, uint32_t gt_channels,
                        float ssim_weight, uint32_t ssim_window, float grad_scale, float *loss, float *v_pred,

@@ -21,13 +21,13 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _torch_loss(pred, gt, ssim_weight):
+def _torch_loss(pred, gt, ssim_weight, window=11):
     """train.rs:243-268 with the 2-D window of ssim.rs:36-40 (not the separable form)."""
     import torch
     import torch.nn.functional as F
 
-    g = torch.tensor([math.exp(-((x - 5) ** 2) / (2.0 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32,
-                     device=pred.device)
+    g = torch.tensor([math.exp(-((x - window // 2) ** 2) / (2.0 * 1.5 ** 2)) for x in range(window)],
+                     dtype=torch.float32, device=pred.device)
     g = g / g.sum()
     w2 = torch.outer(g, g)[None, None].repeat(3, 1, 1, 1)
     pred_rgb = pred[..., :3]
@@ -35,7 +35,7 @@ def _torch_loss(pred, gt, ssim_weight):
     loss = (cmp - gt).abs().mean()
     if ssim_weight > 0:
         x, y = pred_rgb[None].permute(0, 3, 1, 2), gt[None, ..., :3].permute(0, 3, 1, 2)
-        blur = lambda t: F.conv2d(t, w2, None, stride=1, padding=6, groups=3)
+        blur = lambda t: F.conv2d(t, w2, None, stride=1, padding=-(-window // 2), groups=3)  # div_ceil, ssim.rs:49
         mu_x, mu_y = blur(x), blur(y)
         s_xx = (blur(x * x) - mu_x * mu_x).clamp_min(0)
         s_yy = (blur(y * y) - mu_y * mu_y).clamp_min(0)
@@ -46,9 +46,13 @@ def _torch_loss(pred, gt, ssim_weight):
     return loss
 
 
-@pytest.mark.parametrize("w,h,gtc,ssim_w,scale", [(123, 82, 3, 0.2, 1.0), (64, 64, 4, 0.2, 0.5), (200, 37, 3, 0.0, 1.0),
-                                                  (33, 95, 4, 0.0, 0.25), (31, 9, 3, 0.5, 1.0), (1920, 1080, 3, 0.2, 1.0)])
-def test_l1_ssim_loss_matches_torch(dev, w, h, gtc, ssim_w, scale):
+@pytest.mark.parametrize("w,h,gtc,ssim_w,scale,window",
+                         [(123, 82, 3, 0.2, 1.0, 11), (64, 64, 4, 0.2, 0.5, 11), (200, 37, 3, 0.0, 1.0, 11),
+                          (33, 95, 4, 0.0, 0.25, 11), (31, 9, 3, 0.5, 1.0, 11), (1920, 1080, 3, 0.2, 1.0, 11),
+                          # other TrainConfig::ssim_window_size values (train.rs:63): every compiled odd size
+                          (123, 82, 3, 0.2, 1.0, 3), (97, 131, 4, 0.2, 1.0, 5), (123, 82, 3, 0.3, 0.5, 7),
+                          (150, 40, 3, 0.2, 1.0, 9), (123, 82, 4, 0.2, 1.0, 13), (260, 75, 3, 0.2, 1.0, 15)])
+def test_l1_ssim_loss_matches_torch(dev, w, h, gtc, ssim_w, scale, window):
     import torch
 
     from brush_amd.train import l1_ssim_loss
@@ -58,9 +62,9 @@ def test_l1_ssim_loss_matches_torch(dev, w, h, gtc, ssim_w, scale):
     gt = torch.rand((h, w, gtc), device=dev)
     gt[: h // 2] = (pred[: h // 2, :, :gtc] + 0.05 * torch.randn((h // 2, w, gtc), device=dev)).clamp(0, 1)  # correlated part
     gt[0, 0] = pred[0, 0, :gtc]  # exact ties: sign(0) = 0
-    loss, v_pred = l1_ssim_loss(pred, gt, ssim_w, 11, scale)
+    loss, v_pred = l1_ssim_loss(pred, gt, ssim_w, window, scale)
     p = pred.clone().requires_grad_(True)
-    want = _torch_loss(p, gt, ssim_w)
+    want = _torch_loss(p, gt, ssim_w, window)
     (want * scale).backward()
     assert abs(float(loss) - float(want)) <= 2e-6 + 1e-5 * abs(float(want))
     ref = p.grad
@@ -79,8 +83,9 @@ def test_l1_ssim_loss_rejects_bad_arguments(dev):
     pred = torch.rand((8, 8, 4), device=dev)
     with pytest.raises(ValueError):
         l1_ssim_loss(pred, torch.rand((8, 8, 2), device=dev), 0.2)
-    with pytest.raises(_lib.BrushError):
-        l1_ssim_loss(pred, torch.rand((8, 8, 3), device=dev), 0.2, window=7)
+    for bad in (4, 1, 17):  # even windows change the map size (ssim.rs:49); sizes above 15 are not compiled
+        with pytest.raises(_lib.BrushError):
+            l1_ssim_loss(pred, torch.rand((8, 8, 3), device=dev), 0.2, window=bad)
 
 
 @pytest.mark.parametrize("n,deg,vjp", [(1024, 3, 0), (1003, 1, 1), (5, 0, 0), (4096, 2, 1)])
