@@ -45,7 +45,8 @@ constexpr uint32_t kCullBlock = kThreads * kCullPerThread;  // splats per cull w
 // If the queue is full the lane falls back to walking its bbox inline (slow, still correct).
 // The hit masks are kept so that the emission pass never repeats the exact test.
 constexpr uint32_t kSmallArea = 16;      // few visible splats (latency-bound launch): short inline walks
-constexpr uint32_t kSmallAreaMany = 64;  // many visible splats (throughput-bound): everything one hit mask can hold
+constexpr uint32_t kSmallAreaMany = 64;
+constexpr uint32_t kHalfWaveSplats = 1u << 18;  // up to this many visible splats a ProjectVisible wave takes 32 of them  // many visible splats (throughput-bound): everything one hit mask can hold
 constexpr uint32_t kChunkTiles = 64;   // one 64-bit hit mask per queue item
 constexpr uint32_t kWalkGroupMax = 16;  // queue items a consumer wave takes at a time when the queue is long
 // Few items: small groups (more waves, shorter serial chains); many items: amortise the memory phase.
@@ -427,10 +428,15 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
     // Tail of global_from_compact_gid (never written by the sort) := 0.
     for (uint32_t i = V + blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
         global_from_compact[i] = 0;
-    // Block-uniform trip count: the queue reservation below is a wave-level collective.
-    for (uint32_t base = blockIdx.x * kThreads; base < V; base += gridDim.x * kThreads) {
-        const uint32_t c = base + threadIdx.x;
-        const bool active = c < V;
+    // Few visible splats: the launch is bound by the latency of one wave's chain (gather, queue reservation, walk
+    // rounds), so a wave takes 32 splats instead of 64 (twice the waves, half the walk rounds each).
+    const uint32_t spw = V <= kHalfWaveSplats ? 32u : kWave;
+    const uint32_t num_waves = gridDim.x * (kThreads / kWave);
+    // Wave-uniform trip count: the queue reservation below is a wave-level collective.
+    for (uint32_t wbase = (blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave) * spw; wbase < V;
+         wbase += num_waves * spw) {
+        const uint32_t c = wbase + lane_id();
+        const bool active = c < V && lane_id() < spw;
         float xy[2] = {0.f, 0.f}, conic[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
         float opac = 0.f;
         uint32_t bb[4] = {0, 0, 0, 0};
