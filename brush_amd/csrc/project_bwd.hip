@@ -652,9 +652,10 @@ __global__ __launch_bounds__(kThreads) void k_project_backward_records(
     }
 }
 
-// index[v * n + gid] = row of splat gid in view v's records.  Never reset: a reader validates an entry by
-// checking row < view_rows[v] and records[v][row].gid == gid (a gid appears at most once per view), so stale
-// entries of earlier steps are harmless.
+// index[v * n + gid] = row of splat gid in view v's records.  A reader validates an entry by checking
+// row < view_rows[v] and records[v][row].gid == gid (a gid appears at most once per view), so stale or uninitialised
+// entries are harmless; it clears the entries it consumes, so a buffer that started as all-ones stays clean and the
+// check of an entry nobody wrote this step costs no gather.
 __global__ __launch_bounds__(kThreads) void k_build_view_index(const float4 *__restrict__ records, uint32_t num_views,
                                                                uint32_t rows_per_view,
                                                                const uint32_t *__restrict__ view_rows, uint32_t n,
@@ -668,12 +669,50 @@ __global__ __launch_bounds__(kThreads) void k_build_view_index(const float4 *__r
     }
 }
 
-template <int DEG, bool ADAM>
-__global__ __launch_bounds__(kThreads) void k_reduce_view_records(
+// The per-view sums of one splat (fixed view order: the same bits on every rank).  `add_sh(Y, v_rgb)` accumulates the
+// splat's v_sh row wherever the caller keeps it.  A consumed index entry is cleared, so a buffer that was all-ones before
+// its first use stays free of stale entries (the record is still checked: correctness never depends on that).
+struct ViewSums {
+    float mean[3] = {0.f, 0.f, 0.f}, scale[3] = {0.f, 0.f, 0.f}, quat[4] = {0.f, 0.f, 0.f, 0.f};
+    float opac = 0.f, stat_norm = 0.f, stat_count = 0.f;
+};
+template <int DEG, typename AddSh>
+__device__ __forceinline__ void sum_view_records(const float4 *__restrict__ records, uint32_t num_views,
+                                                 uint32_t rows_per_view, const uint32_t *__restrict__ view_rows,
+                                                 const float *__restrict__ campos, uint32_t *__restrict__ index,
+                                                 const float *means, uint32_t n, uint32_t g, ViewSums &o, AddSh add_sh) {
+    constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
+    const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
+    for (uint32_t v = 0; v < num_views; v++) {
+        const uint32_t r = index[(size_t)v * n + g];
+        if (r >= min(view_rows[v], rows_per_view)) continue;
+        const float4 *rec = records + ((size_t)v * rows_per_view + r) * (kRecFloats / 4);
+        const float4 a = rec[0];
+        if (__float_as_uint(a.x) != g) continue;  // stale index entry
+        index[(size_t)v * n + g] = kInvalid;
+        const float4 b = rec[1], c = rec[2], d = rec[3];
+        o.mean[0] += a.y, o.mean[1] += a.z, o.mean[2] += a.w;
+        o.scale[0] += b.x, o.scale[1] += b.y, o.scale[2] += b.z;
+        o.quat[0] += b.w, o.quat[1] += c.x, o.quat[2] += c.y, o.quat[3] += c.z;
+        o.opac += c.w;
+        o.stat_norm += d.w;
+        o.stat_count += 1.0f;
+        // gather_grads.wgsl:182-222 with this view's camera term (viewmat[3].xyz)
+        float dir[3] = {mean[0] - campos[v * 3], mean[1] - campos[v * 3 + 1], mean[2] - campos[v * 3 + 2]};
+        const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        dir[0] = dir[0] / len, dir[1] = dir[1] / len, dir[2] = dir[2] / len;
+        float Y[ncoef];
+        sh_basis<ncoef>(DEG, dir, Y);
+        add_sh(Y, d);
+    }
+}
+
+// Fused with Adam: the summed rows go through the per-wave LDS staging of store_gradients_or_step.
+template <int DEG>
+__global__ __launch_bounds__(kThreads) void k_reduce_view_records_adam(
     const float4 *__restrict__ records, uint32_t num_views, uint32_t rows_per_view,
-    const uint32_t *__restrict__ view_rows, const float *__restrict__ campos, const uint32_t *__restrict__ index,
-    const float *means, uint32_t n, float *__restrict__ v_means, float *__restrict__ v_scales,
-    float *__restrict__ v_quats, float *__restrict__ v_sh, float *__restrict__ v_opac, AdamFuse af) {
+    const uint32_t *__restrict__ view_rows, const float *__restrict__ campos, uint32_t *__restrict__ index,
+    const float *means, uint32_t n, AdamFuse af) {
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
     constexpr uint32_t kRow = ncoef * 3, kRowPad = kRow | 1u;
     constexpr uint32_t kStageFloats = (kWave * kRowPad > 512u ? kWave * kRowPad : 512u);
@@ -683,44 +722,71 @@ __global__ __launch_bounds__(kThreads) void k_reduce_view_records(
     const uint32_t g0 = blockIdx.x * kThreads + wv * kWave;
     if (g0 >= n) return;  // wave-uniform; the kernel has no workgroup barrier
     const uint32_t g = g0 + lane;
-    float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_quat[4] = {0.f, 0.f, 0.f, 0.f};
-    float o_opac = 0.f, stat_norm = 0.f, stat_count = 0.f;
+    ViewSums o;
     float *row = stage + lane * kRowPad;
 #pragma unroll
     for (uint32_t k = 0; k < kRow; k++) row[k] = 0.f;
-    if (g < n) {
-        const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
-        for (uint32_t v = 0; v < num_views; v++) {  // fixed order: the same bits on every rank
-            const uint32_t r = index[(size_t)v * n + g];
-            if (r >= min(view_rows[v], rows_per_view)) continue;
-            const float4 *rec = records + ((size_t)v * rows_per_view + r) * (kRecFloats / 4);
-            const float4 a = rec[0];
-            if (__float_as_uint(a.x) != g) continue;  // stale index entry
-            const float4 b = rec[1], c = rec[2], d = rec[3];
-            o_mean[0] += a.y, o_mean[1] += a.z, o_mean[2] += a.w;
-            o_scale[0] += b.x, o_scale[1] += b.y, o_scale[2] += b.z;
-            o_quat[0] += b.w, o_quat[1] += c.x, o_quat[2] += c.y, o_quat[3] += c.z;
-            o_opac += c.w;
-            stat_norm += d.w;
-            stat_count += 1.0f;
-            // gather_grads.wgsl:182-222 with this view's camera term (viewmat[3].xyz)
-            float dir[3] = {mean[0] - campos[v * 3], mean[1] - campos[v * 3 + 1], mean[2] - campos[v * 3 + 2]};
-            const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-            dir[0] = dir[0] / len, dir[1] = dir[1] / len, dir[2] = dir[2] / len;
-            float Y[ncoef];
-            sh_basis<ncoef>(DEG, dir, Y);
+    if (g < n)
+        sum_view_records<DEG>(records, num_views, rows_per_view, view_rows, campos, index, means, n, g, o,
+                              [&](const float *Y, const float4 &d) {
 #pragma unroll
-            for (uint32_t k = 0; k < ncoef; k++) {
-                row[k * 3 + 0] += Y[k] * d.x;
-                row[k * 3 + 1] += Y[k] * d.y;
-                row[k * 3 + 2] += Y[k] * d.z;
-            }
+                                  for (uint32_t k = 0; k < ncoef; k++) {
+                                      row[k * 3 + 0] += Y[k] * d.x;
+                                      row[k * 3 + 1] += Y[k] * d.y;
+                                      row[k * 3 + 2] += Y[k] * d.z;
+                                  }
+                              });
+    const float zero2[2] = {0.f, 0.f}, zero3[3] = {0.f, 0.f, 0.f};
+    store_gradients_or_step<DEG, true, true>(af, n, g0, lane, stage, o.mean, o.scale, o.quat, o.opac, zero2, o.stat_norm,
+                                             o.stat_count, nullptr, zero3, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                             nullptr);
+}
+
+// Dense sum: like the dense backward, the zeros of the splats no view sees are stored straight from registers by the
+// lanes that own the addresses, and a splat some view sees keeps its v_sh row in registers and writes its rows itself.
+template <int DEG>
+__global__ __launch_bounds__(kThreads) void k_reduce_view_records_dense(
+    const float4 *__restrict__ records, uint32_t num_views, uint32_t rows_per_view,
+    const uint32_t *__restrict__ view_rows, const float *__restrict__ campos, uint32_t *__restrict__ index,
+    const float *means, uint32_t n, float *__restrict__ v_means, float *__restrict__ v_scales,
+    float *__restrict__ v_quats, float *__restrict__ v_sh, float *__restrict__ v_opac) {
+    constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
+    constexpr uint32_t kRow = ncoef * 3;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t g0 = blockIdx.x * kThreads + (threadIdx.x / kWave) * kWave;
+    if (g0 >= n) return;  // wave-uniform; the kernel has no workgroup barrier
+    const size_t g = (size_t)g0 + lane;
+    ViewSums o;
+    float row[kRow];
+#pragma unroll
+    for (uint32_t k = 0; k < kRow; k++) row[k] = 0.f;
+    if (g < n)
+        sum_view_records<DEG>(records, num_views, rows_per_view, view_rows, campos, index, means, n, (uint32_t)g, o,
+                              [&](const float *Y, const float4 &d) {
+#pragma unroll
+                                  for (uint32_t k = 0; k < ncoef; k++) {
+                                      row[k * 3 + 0] += Y[k] * d.x;
+                                      row[k * 3 + 1] += Y[k] * d.y;
+                                      row[k * 3 + 2] += Y[k] * d.z;
+                                  }
+                              });
+    const bool seen = o.stat_count != 0.0f;
+    zero_invisible_rows<DEG>(n, g0, lane, __ballot(seen), v_means, nullptr, v_scales, v_quats, v_sh, v_opac);
+    if (seen) {
+        reinterpret_cast<float4 *>(v_quats)[g] = make_float4(o.quat[0], o.quat[1], o.quat[2], o.quat[3]);
+        v_opac[g] = o.opac;
+#pragma unroll
+        for (int k = 0; k < 3; k++) v_means[g * 3 + k] = o.mean[k], v_scales[g * 3 + k] = o.scale[k];
+        float *dst = v_sh + g * kRow;
+        if constexpr (kRow % 4 == 0) {
+#pragma unroll
+            for (uint32_t j = 0; j < kRow / 4; j++)
+                reinterpret_cast<float4 *>(dst)[j] = make_float4(row[4 * j], row[4 * j + 1], row[4 * j + 2], row[4 * j + 3]);
+        } else {
+#pragma unroll
+            for (uint32_t e = 0; e < kRow; e++) dst[e] = row[e];
         }
     }
-    const float zero2[2] = {0.f, 0.f}, zero3[3] = {0.f, 0.f, 0.f};
-    store_gradients_or_step<DEG, ADAM, true>(af, n, g0, lane, stage, o_mean, o_scale, o_quat, o_opac, zero2, stat_norm,
-                                             stat_count, nullptr, zero3, v_means, nullptr, v_scales, v_quats, v_sh,
-                                             v_opac);
 }
 
 }  // namespace
@@ -791,11 +857,11 @@ hipError_t launch_reduce_view_records(const float *records, uint32_t num_views, 
     if (adam) af = *adam;
 #define BRUSH_LAUNCH_RV(D)                                                                                         \
     if (adam)                                                                                                      \
-        hipLaunchKernelGGL((k_reduce_view_records<D, true>), grid, block, 0, s, rec4, num_views, rows_per_view,    \
-                           view_rows, campos, index, means, n, v_means, v_scales, v_quats, v_sh, v_opac, af);      \
+        hipLaunchKernelGGL((k_reduce_view_records_adam<D>), grid, block, 0, s, rec4, num_views, rows_per_view,     \
+                           view_rows, campos, index, means, n, af);                                                \
     else                                                                                                           \
-        hipLaunchKernelGGL((k_reduce_view_records<D, false>), grid, block, 0, s, rec4, num_views, rows_per_view,   \
-                           view_rows, campos, index, means, n, v_means, v_scales, v_quats, v_sh, v_opac, af)
+        hipLaunchKernelGGL((k_reduce_view_records_dense<D>), grid, block, 0, s, rec4, num_views, rows_per_view,    \
+                           view_rows, campos, index, means, n, v_means, v_scales, v_quats, v_sh, v_opac)
     switch (sh_degree) {
         case 0: BRUSH_LAUNCH_RV(0); break;
         case 1: BRUSH_LAUNCH_RV(1); break;

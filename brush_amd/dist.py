@@ -288,7 +288,8 @@ class ViewExchange:
         nbytes = C.c_size_t()
         _lib.check(_lib.lib().brush_view_index_size(self.n, self.world, C.byref(nbytes)), "brush_view_index_size")
         if self.index is None or self.index.numel() < nbytes.value:
-            self.index = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+            # all-ones = "no row": the reduction clears what it consumes, so the buffer never holds stale entries
+            self.index = torch.full((nbytes.value,), 0xFF, dtype=torch.uint8, device=self.device)
         recs = self.gathered[:self.world * self._rows * _REC]
         view_rows = self.metas[:, 0].contiguous()
         campos = self.metas[:, 1:4].contiguous().view(torch.float32)

@@ -184,8 +184,10 @@ int brush_render_backward_records(const BrushUniforms *h_uniforms, const BrushAu
                                   const float *log_scales, const float *quats, const float *raw_opacity, uint32_t n,
                                   const float *out_img, const float *v_out, float *records, uint32_t max_rows,
                                   void *workspace, size_t workspace_bytes, brush_stream_t stream);
-/* Scratch of the reduction: num_views * n u32 (row of splat g in view v's records).  It needs no initialisation
- * and no reset between steps: entries are validated against the record they point to. */
+/* Scratch of the reduction: num_views * n u32 (row of splat g in view v's records).  Results never depend on its
+ * contents (entries are validated against the record they point to), but set it to 0xFF bytes once before the first
+ * use: the reduction clears the entries it consumes, so from then on an entry nobody wrote this step is recognised
+ * without a gather.  No reset between steps. */
 int brush_view_index_size(uint32_t n, uint32_t num_views, size_t *bytes);
 /* Sum over views -> dense gradients.  records: [num_views][rows_per_view][16]; view v owns its first
  * view_rows[v] rows (device array [num_views], values > rows_per_view are clamped); campos: [num_views][3] =
