@@ -4,29 +4,26 @@
 //   Rasterize           crates/brush-render/src/shaders/rasterize.wgsl:20-115
 //   RasterizeBackwards  crates/brush-render/src/shaders/rasterize_backwards.wgsl:140-304
 //
-// gfx950 layout (both kernels): ONE wave64 per 16x16 tile, FOUR horizontally adjacent pixels
-// per lane (lane l -> row l/4, columns 4*(l%4)..+3).  A single-wave workgroup needs no
-// s_barrier and no LDS atomics; the tile's depth-sorted splat list is staged in LDS in batches
-// of 64 records (one gathered 36-byte record per lane) and read back as wave-uniform
-// broadcasts (2 x ds_read_b128 + 1 x ds_read_b32 per splat, shared by 4 pixel evaluations per
-// lane).  Workgroups are dealt to XCDs round-robin, so block ids are remapped to give every
-// XCD a contiguous band of tiles: neighbouring tiles gather the same splat records from one L2.
+// gfx950 layout: pixels of an 8x8 QUADRANT of a 16x16 tile map to the 64 lanes of a wave (lane = x + 8 y), the tile's
+// depth-sorted splat list is staged in LDS in batches of 64 records (one gathered 36-byte record per lane) and read back
+// as wave-uniform broadcasts, and a (record, quadrant) pair whose alpha provably stays below 1/255 on the whole quadrant
+// is skipped by a scalar branch (see "footprint-aware kernels" below).  Workgroups are dealt to XCDs round-robin, so
+// block ids are remapped to give every XCD a contiguous band of tiles: neighbouring tiles gather the same splat records
+// from one L2.  Waves of a workgroup never exchange data: no s_barrier, no LDS atomics.
 //
-// Forward: identical arithmetic to the reference per pixel; the wave leaves the list as soon as
-// all of its 256 pixels have saturated (the reference walks every batch, rasterize.wgsl:57-101;
-// same result).
+// Forward: one wave per quadrant (4 waves = 1 tile per workgroup); identical arithmetic to the reference per pixel; the
+// wave leaves the list as soon as all of its pixels have saturated (the reference walks every batch,
+// rasterize.wgsl:57-101; same result).
 //
-// Backward: replaces the reference's LDS gradient queue + nine software CAS loops per queued
-// gradient (rasterize_backwards.wgsl:47-135,276-301).  Each lane first sums the 9 gradient
-// components over its 4 pixels (fused into the FMAs), then ONE wave64 DPP reduction per
-// component (row_shr 1/2/4/8 + row_bcast 15/31, pure VALU) leaves the tile total in lane 63,
-// which parks it in an LDS row.  When a batch retires, the [64][9] block is flushed with
-// hardware global_atomic_add_f32 in a shape where consecutive lanes hit consecutive components
-// of one splat (contiguous 36-byte segments).  Splats that touch no pixel of the tile skip the
-// reduction.
+// Backward: replaces the reference's LDS gradient queue + nine software CAS loops per queued gradient
+// (rasterize_backwards.wgsl:47-135,276-301).  One wave per tile, one pixel per lane PER QUADRANT: a lane sums the 9
+// gradient components over its quadrants in registers, then ONE transposing wave64 reduction (v_permlane32/16_swap +
+// DPP row sums, 26 VALU) parks the tile totals in an LDS row.  When a batch retires the [64][9] block is flushed with
+// hardware global_atomic_add_f32, consecutive lanes on consecutive components of one splat's 64-byte compact row: the L2
+// executes float atomics line by line.  Records that touch no pixel of the tile skip reduction and flush.
 //
-// Roofline: both kernels are fp32-VALU / v_exp_f32 bound, not HBM bound (256 pixel evaluations
-// per 40-byte intersection record); DESIGN.md states both ceilings.
+// Roofline: both kernels are bound by fp32 VALU issue (and the backward by the L2's atomic rate), not by HBM;
+// DESIGN.md states the ceilings and the measurements.
 #include <stdlib.h>
 
 #include "internal.hpp"
@@ -35,172 +32,14 @@ namespace brush {
 namespace {
 
 constexpr uint32_t kBatch = kWave;  // 64 splats per LDS batch, one per lane
-// Pixels per lane PIX is a template parameter: 4 (one wave64 per tile) when the frame has enough
-// tiles to fill the chip, 2 (two waves per tile, 8 rows each) for small frames, where one wave
-// per tile would leave most SIMDs with a single latency-bound wave.
-
-// Pixels are processed in pairs held in float2 vectors: the arithmetic compiles to packed
-// v_pk_{mul,add,fma}_f32 (two pixels per VALU issue slot); only exp / rcp / min / compares /
-// selects stay per element.  Both raster kernels are VALU-issue bound.
-typedef float f2 __attribute__((ext_vector_type(2)));
-template <uint32_t N>
-__device__ __forceinline__ bool any_of(const bool (&b)[N]) {
-    bool r = false;
-#pragma unroll
-    for (uint32_t i = 0; i < N; i++) r = r || b[i];
-    return r;
-}
-__device__ __forceinline__ f2 splat2(float v) { return (f2){v, v}; }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 exp2_2(f2 v) { return (f2){__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
-__device__ __forceinline__ f2 min2(float lim, f2 v) { return (f2){fminf(lim, v.x), fminf(lim, v.y)}; }
-__device__ __forceinline__ f2 sel2(bool cx, bool cy, f2 a, f2 b) { return (f2){cx ? a.x : b.x, cy ? a.y : b.y}; }
 constexpr float kNegLog2e = -1.44269504088896341f;  // exp(-s) = exp2(kNegLog2e * s)
-
-struct SplatLds {
-    float4 a[kBatch];  // xy.x, xy.y, conic.x, conic.y
-    float4 b[kBatch];  // conic.z, r, g, b
-    float o[kBatch];   // opacity
-};
-
-__device__ __forceinline__ void stage_splat(SplatLds &lds, uint32_t slot, const float *__restrict__ p) {
-    lds.a[slot] = make_float4(p[0], p[1], p[2], p[3]);
-    lds.b[slot] = make_float4(p[4], p[5], p[6], p[7]);
-    lds.o[slot] = p[8];
-}
 
 constexpr uint32_t kTilesPerBlock = 4;  // 4 independent wave64s per 256-thread workgroup
 constexpr uint32_t kRasterThreads = kTilesPerBlock * kWave;
 
-// Every XCD (blocks b, b+8, b+16, ... share one) gets a contiguous band of work units; wave `wv`
-// of block `bid` takes one unit (a tile, or half a tile when PIX = 2).  The grid has a multiple
-// of 8 blocks.
-__device__ __forceinline__ uint32_t xcd_unit(uint32_t bid, uint32_t nblocks, uint32_t wv) {
-    const uint32_t per = nblocks >> 3;
-    return ((bid & 7u) * per + (bid >> 3)) * kTilesPerBlock + wv;
-}
-// Pixel block of a lane: PIX horizontally adjacent pixels.  PIX = 4: lane l -> row l/4, columns
-// 4*(l%4)..; PIX = 2: wave `sub` of the tile owns rows 8*sub..8*sub+7, lane l -> row l/8, columns 2*(l%8)..
-template <uint32_t PIX>
-struct LaneMap {
-    static constexpr uint32_t kLanesPerRow = kTileWidth / PIX;
-    static constexpr uint32_t kRowsPerWave = kWave / kLanesPerRow;
-    static constexpr uint32_t kWavesPerTile = kTileWidth / kRowsPerWave;
-    static constexpr uint32_t kPairs = PIX / 2;
-};
 // The waves of a workgroup never exchange data: LDS hand-offs are wave-local, the LDS queue of a
 // wave is in order, so a compiler-level barrier is all that is needed (no s_barrier).
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
-
-template <bool RASTER_U32, uint32_t PIX>
-__global__ __launch_bounds__(kRasterThreads) void k_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles,
-                                                     const uint32_t *__restrict__ gid_from_isect,
-                                                     const uint32_t *__restrict__ tile_bins,
-                                                     const float *__restrict__ projected,
-                                                     void *__restrict__ out_img,
-                                                     uint32_t *__restrict__ final_index, uint32_t u32_pitch) {
-    __shared__ SplatLds lds_all[kTilesPerBlock];
-    using M = LaneMap<PIX>;
-    constexpr uint32_t kPix = PIX, kPairs = M::kPairs;
-    const uint32_t wv = threadIdx.x / kWave;
-    SplatLds &lds = lds_all[wv];
-    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x, wv);
-    const uint32_t tile_id = unit / M::kWavesPerTile, sub = unit % M::kWavesPerTile;
-    if (tile_id >= num_tiles) return;
-    const uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t px0 = tile_x * kTileWidth + (lane % M::kLanesPerRow) * kPix;
-    const uint32_t py = tile_y * kTileWidth + sub * M::kRowsPerWave + lane / M::kLanesPerRow;
-    const float pcy = (float)py + 0.5f;  // rasterize.wgsl:32
-    const float pcx0 = (float)px0 + 0.5f;
-
-    // Per-pair state: T (output transmittance), colour sums, last contributing isect; `live`
-    // is false once a pixel has saturated or lies outside the image.
-    bool live[kPix];
-    f2 T[kPairs], cr[kPairs], cg[kPairs], cb[kPairs];
-    uint32_t fin[kPix];
-#pragma unroll
-    for (uint32_t j = 0; j < kPix; j++) {
-        live[j] = px0 + j < w && py < h;
-        fin[j] = 0;
-    }
-#pragma unroll
-    for (uint32_t p = 0; p < kPairs; p++) {
-        T[p] = splat2(1.0f);
-        cr[p] = cg[p] = cb[p] = splat2(0.0f);
-    }
-
-    const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
-    for (uint32_t batch_start = r0; batch_start < r1; batch_start += kBatch) {
-        if (__ballot(any_of<kPix>(live)) == 0ull) break;
-        const uint32_t remaining = min(kBatch, r1 - batch_start);
-        wave_sync();
-        if (lane < remaining) {
-            const uint32_t cg_id = gid_from_isect[batch_start + lane];
-            stage_splat(lds, lane, projected + (size_t)cg_id * BRUSH_PROJECTED_FLOATS);
-        }
-        wave_sync();
-        for (uint32_t t = 0; t < remaining; t++) {
-            const float4 a = lds.a[t];
-            const float4 b = lds.b[t];
-            const float opac = lds.o[t];
-            const float dy = a.y - pcy;
-            const float cdy2 = b.x * dy * dy;
-            const float bdy = a.w * dy;
-            const float dx0 = a.x - pcx0;
-#pragma unroll
-            for (uint32_t p = 0; p < kPairs; p++) {
-                // rasterize.wgsl:80-99 for pixels 2p, 2p+1, branch-free
-                const f2 dx = splat2(dx0) - (f2){(float)(2 * p), (float)(2 * p + 1)};
-                const f2 sigma = fma2(splat2(0.5f), fma2(splat2(a.z) * dx, dx, splat2(cdy2)), splat2(bdy) * dx);
-                const f2 vis = exp2_2(sigma * kNegLog2e);
-                const f2 alpha = min2(0.999f, splat2(opac) * vis);
-                const f2 next_T = T[p] * (1.0f - alpha);
-                const bool hx = live[2 * p] && sigma.x >= 0.0f && alpha.x >= 1.0f / 255.0f;
-                const bool hy = live[2 * p + 1] && sigma.y >= 0.0f && alpha.y >= 1.0f / 255.0f;
-                const bool sx = hx && next_T.x <= 1e-4f, sy = hy && next_T.y <= 1e-4f;  // :88-91
-                const bool ax = hx && !sx, ay = hy && !sy;
-                const f2 fac = sel2(ax, ay, alpha * T[p], splat2(0.0f));
-                cr[p] = fma2(splat2(b.y), fac, cr[p]);
-                cg[p] = fma2(splat2(b.z), fac, cg[p]);
-                cb[p] = fma2(splat2(b.w), fac, cb[p]);
-                T[p] = sel2(ax, ay, next_T, T[p]);
-                fin[2 * p] = ax ? batch_start + t : fin[2 * p];
-                fin[2 * p + 1] = ay ? batch_start + t : fin[2 * p + 1];
-                live[2 * p] = live[2 * p] && !sx;
-                live[2 * p + 1] = live[2 * p + 1] && !sy;
-            }
-            if (__ballot(any_of<kPix>(live)) == 0ull) break;
-        }
-    }
-
-    if (py < h) {
-#pragma unroll
-        for (uint32_t j = 0; j < kPix; j++) {
-            if (px0 + j < w) {
-                const size_t pix = (size_t)(px0 + j) + (size_t)py * w;
-                const float Tj = (j & 1) ? T[j / 2].y : T[j / 2].x;
-                const float rj = (j & 1) ? cr[j / 2].y : cr[j / 2].x;
-                const float gj = (j & 1) ? cg[j / 2].y : cg[j / 2].x;
-                const float bj = (j & 1) ? cb[j / 2].y : cb[j / 2].x;
-                const float al = 1.0f - Tj;
-                if (RASTER_U32) {
-                    // rasterize.wgsl:106-109
-                    const uint32_t r8 = (uint32_t)fminf(fmaxf(rj * 255.0f, 0.0f), 255.0f);
-                    const uint32_t g8 = (uint32_t)fminf(fmaxf(gj * 255.0f, 0.0f), 255.0f);
-                    const uint32_t b8 = (uint32_t)fminf(fmaxf(bj * 255.0f, 0.0f), 255.0f);
-                    const uint32_t a8 = (uint32_t)fminf(fmaxf(al * 255.0f, 0.0f), 255.0f);
-                    // rows `u32_pitch` pixels apart (the viewer's 256-byte row pitch, burn_texture.rs:17-26)
-                    static_cast<uint32_t *>(out_img)[(size_t)(px0 + j) + (size_t)py * u32_pitch] =
-                        r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
-                } else {
-                    static_cast<float4 *>(out_img)[pix] = make_float4(rj, gj, bj, al);
-                    final_index[pix] = fin[j];
-                }
-            }
-        }
-    }
-}
 
 // ---- footprint-aware kernels -----------------------------------------------------------------
 //
@@ -405,181 +244,6 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
     v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
     return v;
-}
-
-template <uint32_t PIX>
-__global__ __launch_bounds__(kRasterThreads) void k_rasterize_backward(
-    uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles, const uint32_t *__restrict__ gid_from_isect,
-    const uint32_t *__restrict__ tile_bins, const float *__restrict__ projected,
-    const uint32_t *__restrict__ final_index, const float *__restrict__ out_img,
-    const float *__restrict__ v_out, float *__restrict__ v_compact) {
-    __shared__ SplatLds lds_all[kTilesPerBlock];
-    __shared__ uint32_t lds_gid_all[kTilesPerBlock][kBatch];
-    __shared__ float acc_all[kTilesPerBlock][kBatch][12];  // 9 used; 48-byte rows keep b128 stores aligned
-
-    using M = LaneMap<PIX>;
-    constexpr uint32_t kPix = PIX, kPairs = M::kPairs;
-    const uint32_t wv = threadIdx.x / kWave;
-    SplatLds &lds = lds_all[wv];
-    uint32_t *lds_gid = lds_gid_all[wv];
-    float(*acc)[12] = acc_all[wv];
-    const uint32_t unit = xcd_unit(blockIdx.x, gridDim.x, wv);
-    const uint32_t tile_id = unit / M::kWavesPerTile, sub = unit % M::kWavesPerTile;
-    if (tile_id >= num_tiles) return;
-    const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
-    if (r1 <= r0) return;
-
-    const uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t px0 = tile_x * kTileWidth + (lane % M::kLanesPerRow) * kPix;
-    const uint32_t py = tile_y * kTileWidth + sub * M::kRowsPerWave + lane / M::kLanesPerRow;
-    const float pcy = (float)py + 0.5f;
-    const float pcx0 = (float)px0 + 0.5f;
-
-    // Per-pixel state, kept per pixel pair.  The reference's running colour `buffer`
-    // (rasterize_backwards.wgsl:253-257) only ever appears dotted with the pixel's constant
-    // v_out.rgb, so the scalar D = sum_j fac_j * (c_j . v_rgb) carries the same information;
-    // K = T_final * v_out.a.  Pixels outside the image get fin = -1 so they never contribute.
-    f2 T[kPairs], K[kPairs], D[kPairs], vor[kPairs], vog[kPairs], vob[kPairs];
-    int32_t fin[kPix];
-#pragma unroll
-    for (uint32_t j = 0; j < kPix; j++) {
-        float T_final = 1.0f;
-        float4 vo = make_float4(0.f, 0.f, 0.f, 0.f);
-        fin[j] = -1;
-        if (px0 + j < w && py < h) {
-            const size_t pix = (size_t)(px0 + j) + (size_t)py * w;
-            T_final = 1.0f - out_img[pix * 4 + 3];  // rasterize_backwards.wgsl:163
-            fin[j] = (int32_t)final_index[pix];
-            vo = reinterpret_cast<const float4 *>(v_out)[pix];
-        }
-        const uint32_t p = j / 2;
-        if (j & 1) {
-            T[p].y = T_final; K[p].y = T_final * vo.w; D[p].y = 0.0f;
-            vor[p].y = vo.x; vog[p].y = vo.y; vob[p].y = vo.z;
-        } else {
-            T[p].x = T_final; K[p].x = T_final * vo.w; D[p].x = 0.0f;
-            vor[p].x = vo.x; vog[p].x = vo.y; vob[p].x = vo.z;
-        }
-    }
-
-    // Entries behind the last one any pixel of this tile composited (isect id > max final_index)
-    // fail `isect_id <= final_isect` for every pixel (rasterize_backwards.wgsl:229), so the walk
-    // starts at the tile's largest final index instead of the end of the list.  Exact, and in
-    // saturated scenes it removes almost the whole list (the forward stopped early there too).
-    int32_t max_fin = fin[0];
-#pragma unroll
-    for (uint32_t j = 1; j < kPix; j++) max_fin = max(max_fin, fin[j]);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) max_fin = max(max_fin, __shfl_xor(max_fin, d, 64));
-    const uint32_t walk_end = min(r1, (uint32_t)(max_fin + 1));
-    if (walk_end <= r0) return;
-
-    // Batches walk the list back to front (rasterize_backwards.wgsl:194-208).
-    for (uint32_t batch_end = walk_end; batch_end > r0;) {
-        const uint32_t remaining = min(kBatch, batch_end - r0);
-        wave_sync();  // previous batch fully flushed
-        if (lane < remaining) {
-            const uint32_t cg_id = gid_from_isect[batch_end - 1u - lane];
-            lds_gid[lane] = cg_id;
-            stage_splat(lds, lane, projected + (size_t)cg_id * BRUSH_PROJECTED_FLOATS);
-        }
-        {
-            float4 *row = reinterpret_cast<float4 *>(&acc[lane][0]);
-            row[0] = row[1] = row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        wave_sync();
-
-        for (uint32_t t = 0; t < remaining; t++) {
-            const int32_t isect_id = (int32_t)(batch_end - 1u - t);
-            const float4 a = lds.a[t];
-            const float4 b = lds.b[t];
-            const float opac = lds.o[t];
-            const float dy = a.y - pcy;
-            const float dy2 = dy * dy;
-            const float cdy2 = b.x * dy2;
-            const float bdy = a.w * dy;
-            const float cdy = b.x * dy;
-            const float dx0 = a.x - pcx0;
-            // Pass 1 (cheap): alpha and the contribution mask of the 4 pixels.
-            f2 dx[kPairs], vis[kPairs], alpha[kPairs];
-            bool m[kPix];
-#pragma unroll
-            for (uint32_t p = 0; p < kPairs; p++) {
-                dx[p] = splat2(dx0) - (f2){(float)(2 * p), (float)(2 * p + 1)};
-                const f2 sigma = fma2(splat2(0.5f), fma2(splat2(a.z) * dx[p], dx[p], splat2(cdy2)), splat2(bdy) * dx[p]);
-                vis[p] = exp2_2(sigma * kNegLog2e);
-                alpha[p] = min2(0.99f, splat2(opac) * vis[p]);  // 0.99 here (rasterize_backwards.wgsl:239)
-                m[2 * p] = isect_id <= fin[2 * p] && sigma.x >= 0.0f && alpha[p].x >= 1.0f / 255.0f;
-                m[2 * p + 1] = isect_id <= fin[2 * p + 1] && sigma.y >= 0.0f && alpha[p].y >= 1.0f / 255.0f;
-            }
-            const bool any = __ballot(any_of<kPix>(m)) != 0ull;
-            // Pass 2: rasterize_backwards.wgsl:244-271 with selects; a pixel pair no lane of the
-            // wave contributes to is skipped by a wave-uniform (scalar) branch.
-            f2 gs[kGradComps];
-#pragma unroll
-            for (uint32_t k = 0; k < kGradComps; k++) gs[k] = splat2(0.0f);
-#pragma unroll
-            for (uint32_t p = 0; p < kPairs; p++) {
-                const bool mx = m[2 * p], my = m[2 * p + 1];
-                if (__ballot(mx || my) == 0ull) continue;
-                // v_rcp_f32 (1 ulp) + one Newton step; 1 - alpha >= 0.01 so this is always finite.
-                const f2 om = 1.0f - alpha[p];
-                f2 ra = (f2){__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-                ra = fma2(fma2(-om, ra, splat2(1.0f)), ra, ra);
-                const f2 Tn = T[p] * ra;
-                const f2 fac = alpha[p] * Tn;
-                // v_alpha = (c*T - buffer*ra) . v_rgb + T_final*ra*v_a  (:253-254)
-                //         = T*(c . v_rgb) + ra*(K - D)
-                const f2 cv = fma2(splat2(b.w), vob[p], fma2(splat2(b.z), vog[p], splat2(b.y) * vor[p]));
-                const f2 v_alpha = fma2(Tn, cv, ra * (K[p] - D[p]));
-                T[p] = sel2(mx, my, Tn, T[p]);
-                D[p] = sel2(mx, my, fma2(fac, cv, D[p]), D[p]);
-                const f2 vis_m = sel2(mx, my, vis[p] * v_alpha, splat2(0.0f));  // v_opac term
-                const f2 v_sigma = vis_m * (-opac);                             // 0 when masked
-                const f2 fac_m = sel2(mx, my, fac, splat2(0.0f));
-                const f2 hs = v_sigma * 0.5f;
-                gs[0] = fma2(v_sigma, fma2(splat2(a.z), dx[p], splat2(bdy)), gs[0]);
-                gs[1] = fma2(v_sigma, fma2(splat2(a.w), dx[p], splat2(cdy)), gs[1]);
-                gs[2] = fma2(hs, dx[p] * dx[p], gs[2]);
-                gs[3] = fma2(v_sigma, dx[p] * dy, gs[3]);
-                gs[4] = fma2(hs, splat2(dy2), gs[4]);
-                gs[5] = fma2(fac_m, vor[p], gs[5]);
-                gs[6] = fma2(fac_m, vog[p], gs[6]);
-                gs[7] = fma2(fac_m, vob[p], gs[7]);
-                gs[8] += vis_m;
-            }
-            float g[kGradComps];
-#pragma unroll
-            for (uint32_t k = 0; k < kGradComps; k++) g[k] = gs[k].x + gs[k].y;
-            if (any) {  // wave-uniform: all 64 lanes take part in the reduction
-                // 8 components: two transposing folds (lane-swap + add), then a row-of-16 scan of
-                // the two survivors; component 8 takes the plain 6-step DPP sum.  26 VALU ops.
-                const float u0 = fold_swap32(g[0], g[1]), u1 = fold_swap32(g[2], g[3]);
-                const float u2 = fold_swap32(g[4], g[5]), u3 = fold_swap32(g[6], g[7]);
-                const float w0 = row_sum_lane15(fold_swap16(u0, u1));
-                const float w1 = row_sum_lane15(fold_swap16(u2, u3));
-                const float s8 = wave_sum_lane63(g[8]);
-                if ((lane & 15u) == 15u) {
-                    // row r: w0 holds component ((r&1)<<1 | r>>1), w1 the same + 4
-                    const uint32_t r = lane >> 4;
-                    const uint32_t i0 = ((r & 1u) << 1) | (r >> 1);
-                    acc[t][i0] = w0;
-                    acc[t][4 + i0] = w1;
-                    if (lane == 63) acc[t][8] = s8;
-                }
-            }
-        }
-        wave_sync();
-        // Flush: one hardware float atomic per (tile, splat, component); consecutive lanes take
-        // consecutive components of one splat (MI355X_MICROARCH.md, global float atomics).
-        for (uint32_t f = lane; f < remaining * kGradComps; f += kWave) {
-            const uint32_t t = f / kGradComps, k = f - t * kGradComps;
-            const float v = acc[t][k];
-            if (v != 0.0f) unsafeAtomicAdd(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], v);
-        }
-        batch_end -= remaining;
-    }
 }
 
 // Footprint-aware backward.  A wave owns NQ quadrants of one tile (NQ = 4: one wave per tile, NQ = 2:
@@ -841,60 +505,26 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
 
 }  // namespace
 
-// Development switch (A/B timing in one process): BRUSH_RASTER_LEGACY=1 selects the round-1 kernels
-// (every record evaluated on all 256 pixels).
-static bool legacy_raster() {
-    static const bool v = [] {
-        const char *e = getenv("BRUSH_RASTER_LEGACY");
-        return e && e[0] == '1';
-    }();
-    return v;
-}
-
-// Work units (waves) per tile of the legacy kernels: 1 with 4 pixels per lane when the frame has at
-// least this many tiles, else 2 with 2 pixels per lane.
-constexpr uint32_t kMinTilesForOneWave = 6144;
-
 hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                             const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
                             const float *projected, int raster_u32, uint32_t u32_pitch, void *out_img,
                             uint32_t *final_index, hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
-    if (!legacy_raster()) {
-        // one workgroup (4 quadrant waves) per tile
-        const dim3 grid(ceil_div(tiles, 8u) * 8u), block(kRasterThreads);
-        if (raster_u32)
-            hipLaunchKernelGGL(k_rasterize_quad<true>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
-                               tile_bins, projected, out_img, final_index, u32_pitch);
-        else
-            hipLaunchKernelGGL(k_rasterize_quad<false>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
-                               tile_bins, projected, out_img, final_index, u32_pitch);
-        return hipGetLastError();
-    }
-    const bool wide = tiles >= kMinTilesForOneWave;
-    const uint32_t units = tiles * (wide ? 1u : 2u);
-    const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
-#define BRUSH_RASTER(U32, PIX)                                                                              \
-    hipLaunchKernelGGL((k_rasterize<U32, PIX>), grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect, \
-                       tile_bins, projected, out_img, final_index, u32_pitch)
-    if (raster_u32) {
-        if (wide) BRUSH_RASTER(true, 4); else BRUSH_RASTER(true, 2);
-    } else {
-        if (wide) BRUSH_RASTER(false, 4); else BRUSH_RASTER(false, 2);
-    }
-#undef BRUSH_RASTER
+    // one workgroup (4 quadrant waves) per tile
+    const dim3 grid(ceil_div(tiles, 8u) * 8u), block(kRasterThreads);
+    if (raster_u32)
+        hipLaunchKernelGGL(k_rasterize_quad<true>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
+                           tile_bins, projected, out_img, final_index, u32_pitch);
+    else
+        hipLaunchKernelGGL(k_rasterize_quad<false>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
+                           tile_bins, projected, out_img, final_index, u32_pitch);
     return hipGetLastError();
 }
 
-// Quadrants per wave of the backward: fewer waves per tile keep the per-record wave reduction rare,
-// more waves per tile fill the chip when the frame has few tiles.
+// Quadrants per wave of the backward: fewer waves per tile keep the per-record wave reduction rare (measured at 1080p:
+// 4 quadrants per wave 152 us, 2: 241 us, 1: 389 us), more waves per tile fill the chip when the frame has few tiles.
 static uint32_t backward_quadrants_per_wave(uint32_t tiles) {
-    static const int forced = [] {
-        const char *e = getenv("BRUSH_BWD_NQ");
-        return e ? atoi(e) : 0;
-    }();
-    if (forced == 1 || forced == 2 || forced == 4) return (uint32_t)forced;
     return tiles >= 6144u ? 4u : (tiles >= 2048u ? 2u : 1u);
 }
 
@@ -905,25 +535,18 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
                                      const uint32_t *unsorted_pos, float *rows, hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
-    static const uint32_t tpb = [] {
-        const char *e = getenv("BRUSH_BWD_TPB");
-        const int v = e ? atoi(e) : 4;
-        return (v == 1 || v == 2 || v == 4) ? (uint32_t)v : 4u;
-    }();
     // Waves per SIMD.  The kernel is bound by VALU issue once a SIMD holds 3+ waves, every wave lives for its whole
     // tile and the tiles' lists are about equally long, so the launch proceeds in rounds of (SIMDs x k) waves and a
     // partly filled last round costs as much as a full one: k in {3, 4, 5} is chosen to waste the least of the last
     // round (1080p: 8160 waves on 1024 SIMDs, k = 4 -> 2 rounds, 152 us; k = 5 -> 1.6 rounds, 164 us; k = 3: 177 us).
-    // The registers allow 5 (4 in deterministic mode); fewer are enforced with unused dynamic LDS per workgroup.
+    // The registers allow up to 5; fewer are enforced with unused dynamic LDS per workgroup.  Workgroups of 4 waves
+    // (4 tiles in a row): 1, 2 and 8 measured slower (154 / 157 / 172 vs 142 us).
     static const uint32_t simds = [] {
         int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
         return (uint32_t)cus * 4u;
-    }();
-    static const int forced_waves = [] {
-        const char *e = getenv("BRUSH_BWD_WAVES");
-        return e ? atoi(e) : 0;
     }();
     auto lds_pad_for = [&](uint32_t units, uint32_t max_k) -> uint32_t {
         uint32_t best_k = max_k, best_cost = 0xFFFFFFFFu;
@@ -931,47 +554,27 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
             const uint32_t cost = ceil_div(units, simds * k) * k;  // in wave-rounds per SIMD
             if (cost < best_cost) best_cost = cost, best_k = k;
         }
-        if (forced_waves >= 3 && forced_waves <= 5) best_k = (uint32_t)forced_waves;
         // static LDS is ~6.3 KB per wave: 160 KB / (k waves x 4 SIMDs) per wave admits exactly k workgroups of 4 waves
         return best_k >= 5u ? 0u : (best_k == 4u ? 2048u : 4096u);
     };
-#define BRUSH_RASTER_BWD(NQ, DET, TPB, UNSORTED, ROWS)                                                            \
-    hipLaunchKernelGGL((k_rasterize_backward_quad<NQ, DET, TPB>), dim3(ceil_div(ceil_div(units, TPB), 8u) * 8u),  \
-                       dim3(TPB * kWave), lds_pad * TPB, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins, projected,   \
+#define BRUSH_RASTER_BWD(NQ, DET, UNSORTED, ROWS)                                                                     \
+    hipLaunchKernelGGL((k_rasterize_backward_quad<NQ, DET, kTilesPerBlock>),                                          \
+                       dim3(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), dim3(kRasterThreads),                \
+                       lds_pad * kTilesPerBlock, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins, projected,   \
                        final_index, out_img, v_out, v_compact, UNSORTED, ROWS)
-#define BRUSH_RASTER_BWD_TPB(NQ, DET, UNSORTED, ROWS)                   \
-    do {                                                                \
-        if (tpb == 1) BRUSH_RASTER_BWD(NQ, DET, 1, UNSORTED, ROWS);     \
-        else if (tpb == 2) BRUSH_RASTER_BWD(NQ, DET, 2, UNSORTED, ROWS); \
-        else BRUSH_RASTER_BWD(NQ, DET, 4, UNSORTED, ROWS);              \
-    } while (0)
     if (rows) {  // deterministic mode: one wave per tile, one stored row per intersection
         const uint32_t units = tiles;
         const uint32_t lds_pad = lds_pad_for(units, 4u);
-        BRUSH_RASTER_BWD_TPB(4, true, unsorted_pos, rows);
+        BRUSH_RASTER_BWD(4, true, unsorted_pos, rows);
         return hipGetLastError();
     }
-    if (!legacy_raster()) {
-        const uint32_t nq = backward_quadrants_per_wave(tiles);
-        const uint32_t units = tiles * (4u / nq);
-        const uint32_t lds_pad = lds_pad_for(units, 5u);
-        if (nq == 4) BRUSH_RASTER_BWD_TPB(4, false, nullptr, nullptr);
-        else if (nq == 2) BRUSH_RASTER_BWD_TPB(2, false, nullptr, nullptr);
-        else BRUSH_RASTER_BWD_TPB(1, false, nullptr, nullptr);
-        return hipGetLastError();
-    }
-#undef BRUSH_RASTER_BWD_TPB
+    const uint32_t nq = backward_quadrants_per_wave(tiles);
+    const uint32_t units = tiles * (4u / nq);
+    const uint32_t lds_pad = lds_pad_for(units, 5u);
+    if (nq == 4) BRUSH_RASTER_BWD(4, false, nullptr, nullptr);
+    else if (nq == 2) BRUSH_RASTER_BWD(2, false, nullptr, nullptr);
+    else BRUSH_RASTER_BWD(1, false, nullptr, nullptr);
 #undef BRUSH_RASTER_BWD
-    const bool wide = tiles >= kMinTilesForOneWave;
-    const uint32_t units = tiles * (wide ? 1u : 2u);
-    const dim3 grid(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), block(kRasterThreads);
-    if (wide) {
-        hipLaunchKernelGGL(k_rasterize_backward<4>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
-                           tile_bins, projected, final_index, out_img, v_out, v_compact);
-    } else {
-        hipLaunchKernelGGL(k_rasterize_backward<2>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
-                           tile_bins, projected, final_index, out_img, v_out, v_compact);
-    }
     return hipGetLastError();
 }
 

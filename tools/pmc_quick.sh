@@ -1,7 +1,7 @@
 #!/bin/bash
 # Quick SQ-counter comparison of kernel variants (development aid): tools/pmc_quick.sh <tag> [bench args...]
 # KERNEL_RE selects the kernels (default: the compositing kernels), TRAIN_STEPS > 0 adds the training leg.
-# Environment (BRUSH_RASTER_LEGACY, BRUSH_BWD_NQ, ...) is inherited by the profiled process.
+# The environment (e.g. BRUSH_DETERMINISTIC) is inherited by the profiled process.
 set -e
 TAG=$1; shift
 OUT=gpurun_out/pmcq_$TAG
