@@ -645,7 +645,8 @@ def test_rgba8_row_pitch_matches_padded_u32(dev):
                                        row_pitch=w - 1)
 
 
-def test_view_records_round_trip(dev):
+@pytest.mark.parametrize("deg", [3, 0, 2])  # v_sh rows of whole cache lines (3) and the scalar store paths (0, 2)
+def test_view_records_round_trip(dev, deg):
     """brush_amd.dist: the 64-byte records of one view (brush_render_backward_records) reduced over that single view
     (brush_reduce_view_records) reproduce the op's dense gradients bit for bit: same projection VJP, same SH basis,
     0 + x = x.  (The multi-GPU exchange all-gathers these records instead of all-reducing 52+12C bytes/splat.)"""
@@ -655,7 +656,7 @@ def test_view_records_round_trip(dev):
     from brush_amd import dist as BD
     from brush_amd import render as R
 
-    n, w, h, deg = 50000, 320, 240, 3
+    n, w, h = 50000, 320, 240
     C = (deg + 1) ** 2
     cloud = H.synthetic_cloud(n, deg, seed=6, mean_mult=0.01)
     p = {k: _t(v, dev) for k, v in cloud.items()}
