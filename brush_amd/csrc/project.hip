@@ -431,11 +431,12 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
     // Few visible splats: the launch is bound by the latency of one wave's chain (gather, queue reservation, walk
     // rounds), so a wave takes 32 splats instead of 64 (twice the waves, half the walk rounds each).
     const uint32_t spw = V <= kHalfWaveSplats ? 32u : kWave;
-    const uint32_t num_waves = gridDim.x * (kThreads / kWave);
-    // Wave-uniform trip count: the queue reservation below is a wave-level collective.
-    for (uint32_t wbase = (blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave) * spw; wbase < V;
-         wbase += num_waves * spw) {
-        const uint32_t c = wbase + lane_id();
+    // Block-uniform trip count: the queue reservation below is a workgroup-level collective.
+    __shared__ uint32_t wave_chunks[kThreads / kWave], block_base_s;
+    const uint32_t wv = threadIdx.x / kWave;
+    const uint32_t per_block = (kThreads / kWave) * spw;
+    for (uint32_t bbase = blockIdx.x * per_block; bbase < V; bbase += gridDim.x * per_block) {
+        const uint32_t c = bbase + wv * spw + lane_id();
         const bool active = c < V && lane_id() < spw;
         float xy[2] = {0.f, 0.f}, conic[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
         float opac = 0.f;
@@ -457,17 +458,23 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
             tt = make_tile_test(conic, opac);
         }
         // exact tile count (project_visible.wgsl:244-250): inline for small bboxes, queued otherwise.
-        // Queue slots are reserved with ONE atomicAdd per wave (wave scan of the chunk counts); a
-        // per-lane atomic on the single counter serialises tens of thousands of requests.
+        // Queue slots are reserved by a wave scan of the chunk counts ...
         const uint32_t bbox_tiles = active ? (bb[2] - bb[0]) * (bb[3] - bb[1]) : 0u;
         const uint32_t nchunks = bbox_tiles > small_area ? (bbox_tiles + kChunkTiles - 1) / kChunkTiles : 0u;
         const uint32_t incl = wave_inclusive_scan(nchunks);
         const uint32_t wave_total = __shfl(incl, 63, 64);
-        uint32_t wave_base = 0;
-        if (wave_total) {
-            if (lane_id() == 0) wave_base = atomicAdd(q.counter, wave_total);
-            wave_base = __shfl(wave_base, 0, 64);
+        // ... and ONE atomicAdd per workgroup: the returning atomics of all workgroups hit one address and are
+        // executed one after the other
+        if (lane_id() == 0) wave_chunks[wv] = wave_total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = (wave_chunks[0] + wave_chunks[1]) + (wave_chunks[2] + wave_chunks[3]);
+            block_base_s = tot ? atomicAdd(q.counter, tot) : 0u;
         }
+        __syncthreads();
+        uint32_t wave_base = block_base_s;
+        for (uint32_t w2 = 0; w2 < wv; w2++) wave_base += wave_chunks[w2];
+        __syncthreads();  // the next trip overwrites both
         uint32_t area = 0, slot = kInvalid;
         if (nchunks) {
             const uint32_t first = wave_base + incl - nchunks;
