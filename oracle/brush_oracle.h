@@ -85,6 +85,10 @@ int oracle_render_backward_ex(const OracleUniforms *u, const OracleAux *aux, con
                               float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
                               float *v_xy_local, float *v_conics, float *v_colors, int f32_sums);
 
+/* brush_oracle_f64.c: forward compositing in f64 under the f32 restatement's decisions (pixel-tolerance arbiter) */
+int oracle_rasterize_forward_f64(const OracleUniforms *u, const OracleAux *aux, double *out /* [h,w,4] */,
+                                 double *cond /* optional [h,w]: sensitivity to relative errors of sigma's terms */);
+
 /* brush_oracle_f64.c: the same backward with every value in f64 and the walk's decisions taken as the f32
  * restatement takes them; all outputs f64.  Arbiter for tolerance questions, never a parity reference itself. */
 int oracle_render_backward_f64(const OracleUniforms *u, const OracleAux *aux, const float *means,

@@ -493,3 +493,52 @@ int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux,
     free(rows); free(acc); free(rows_abs); free(acc_abs); free(rows_flip); free(acc_flip);
     return 0;
 }
+
+/* Forward compositing in f64 (rasterize.wgsl:20-115) from the f32 ProjectedSplat records and the f32 tile lists, the
+ * walk's decisions (sigma >= 0, alpha >= 1/255, the saturation stop) taken as the f32 restatement takes them.  out:
+ * [h,w,4] f64.  Arbiter for the pixel tolerance: where the quadratic form cancels heavily (a splat tens of thousands of
+ * pixels wide and far off-screen), an f32 evaluation of sigma with or without fused multiply-adds differs by 1e-7 of the
+ * cancelling terms, i.e. by far more than 1e-7 of sigma, and the reference leaves the contraction to its shader compiler.
+ * cond (optional, [h,w]): first-order bound of what a RELATIVE perturbation of every sigma's terms can move in the pixel,
+ *   2 max(1, max_i |c_i|) sum_i mag_i alpha_i T_i,  mag_i = 0.5 (|a| dx^2 + |c| dy^2) + |b dx dy|
+ * (d out / d sigma_i = -alpha_i T_i (c_i - colour behind i), |c_i - behind| <= 2 max |c|; alpha channel: <= alpha_i T_i). */
+int oracle_rasterize_forward_f64(const OracleUniforms *u, const OracleAux *aux, double *out, double *cond) {
+    const uint32_t w = u->img_size[0], h = u->img_size[1];
+    const uint32_t tbx = u->tile_bounds[0], tby = u->tile_bounds[1];
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t tile = 0; tile < (int64_t)tbx * tby; tile++) {
+        const uint32_t tile_x = (uint32_t)(tile % tbx), tile_y = (uint32_t)(tile / tbx);
+        const uint32_t r0 = aux->tile_bins[tile * 2], r1 = aux->tile_bins[tile * 2 + 1];
+        for (uint32_t ly = 0; ly < 16; ly++)
+            for (uint32_t lx = 0; lx < 16; lx++) {
+                const uint32_t px = tile_x * 16 + lx, py = tile_y * 16 + ly;
+                if (px >= w || py >= h) continue;
+                const float pcx = (float)px + 0.5f, pcy = (float)py + 0.5f;
+                float T = 1.0f;
+                double Td = 1.0, rgb[3] = {0, 0, 0}, sens = 0.0, cmax = 1.0;
+                for (uint32_t i = r0; i < r1; i++) {
+                    const float *p = aux->projected_splats + (size_t)aux->compact_gid_from_isect[i] * 9;
+                    const float dx = p[0] - pcx, dy = p[1] - pcy;
+                    const float sigma = 0.5f * (p[2] * dx * dx + p[4] * dy * dy) + p[3] * dx * dy;
+                    const float alpha = fminf(0.999f, p[8] * expf(-sigma));
+                    if (sigma >= 0.0f && alpha >= 1.0f / 255.0f) {
+                        const float next_T = T * (1.0f - alpha);
+                        if (next_T <= 1e-4f) break;
+                        const double ddx = (double)p[0] - (double)pcx, ddy = (double)p[1] - (double)pcy;
+                        const double sd = 0.5 * ((double)p[2] * ddx * ddx + (double)p[4] * ddy * ddy) + (double)p[3] * ddx * ddy;
+                        const double ad = fmin(0.999, (double)p[8] * exp(-sd));
+                        const double fac = ad * Td;
+                        sens += fac * (0.5 * (fabs((double)p[2]) * ddx * ddx + fabs((double)p[4]) * ddy * ddy) + fabs((double)p[3] * ddx * ddy));
+                        cmax = fmax(cmax, fmax(fabs((double)p[5]), fmax(fabs((double)p[6]), fabs((double)p[7]))));
+                        rgb[0] += (double)p[5] * fac, rgb[1] += (double)p[6] * fac, rgb[2] += (double)p[7] * fac;
+                        Td *= 1.0 - ad;
+                        T = next_T;
+                    }
+                }
+                double *o = out + ((size_t)px + (size_t)py * w) * 4;
+                o[0] = rgb[0], o[1] = rgb[1], o[2] = rgb[2], o[3] = 1.0 - Td;
+                if (cond) cond[(size_t)px + (size_t)py * w] = 2.0 * cmax * sens;
+            }
+    }
+    return 0;
+}

@@ -265,6 +265,23 @@ def render_backward(u: dict, aux: dict, means, log_scales, quats, raw_opac, out_
     return g
 
 
+def rasterize_forward_f64(u: dict, aux: dict):
+    """Forward compositing in f64 from the f32 records and tile lists of `aux`, the walk's decisions as the f32
+    restatement takes them (brush_oracle_f64.c).  Returns (out [h,w,4] float64, cond [h,w] float64): the arbiter of
+    the pixel tolerance and, per pixel, what a relative error eps of the terms of every sigma can move (eps * cond)."""
+    w, h = int(u["img_size"][0]), int(u["img_size"][1])
+    out = np.zeros((h, w, 4), np.float64)
+    cond = np.zeros((h, w), np.float64)
+    s = _Aux()
+    for k in ("projected_splats", "num_intersections", "num_visible", "final_index", "cum_tiles_hit",
+              "tile_bins", "compact_gid_from_isect", "global_from_compact_gid"):
+        setattr(s, k, aux[k].ctypes.data)
+    s.max_intersects = int(aux["max_intersects"])
+    us = _to_struct(u, int(aux["projected_splats"].shape[0]))
+    lib().oracle_rasterize_forward_f64(C.byref(us), C.byref(s), _p(out), _p(cond))
+    return out, cond
+
+
 def render_backward_f64(u: dict, aux: dict, means, log_scales, quats, raw_opac, out_img, v_out):
     """The f64 arbiter (brush_oracle_f64.c): same inputs / forward state, every value in double, the walk's
     decisions as the f32 restatement takes them.  Returns float64 dense grads and, under "mag_<name>", the sum of

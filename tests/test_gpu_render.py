@@ -196,12 +196,27 @@ def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0):
     assert np.array_equal(_np_u32(aux.cum_tiles_hit)[:n], oa["cum_tiles_hit"])
     assert np.array_equal(_np_u32(aux.compact_gid_from_isect)[:I], oa["compact_gid_from_isect"][:I])
     assert np.array_equal(_np_u32(aux.tile_bins), oa["tile_bins"])
-    # composite: 1e-4 L-inf away from pixels where a threshold test is within 1e-5 of flipping
+    # composite: 1e-4 L-inf away from pixels where a threshold test is within 1e-5 of flipping, measured against the
+    # f64 evaluation of the same walk (same f32 records, same decisions).  Where the quadratic form cancels heavily (a
+    # splat tens of thousands of pixels wide, far off-screen) any f32 evaluation of sigma is off by up to ~3 eps32 of
+    # the CANCELLING terms — with or without the fused multiply-adds the reference leaves to its shader compiler — so
+    # the allowance grows with the f64 pass's first-order sensitivity `cond` to exactly that (found by
+    # tools/fuzz_parity.py with the camera inside a dense cloud: the GPU and the f32 restatement are equally far from
+    # f64 there, 1.2e-4 / 1.5e-4 at the 99th percentile, and 6e-4 from each other; on the bench scenes cond is small
+    # and this is the plain 1e-4 test).
     risk = oa["flip_risk"].astype(bool)
-    assert risk.mean() < 2e-3
+    assert risk.mean() < 2e-3 or risk.sum() <= 16  # the fraction means little on a thumbnail-sized image
     diff = np.abs(gpu["out"] - orc["out"]).max(axis=2)
-    assert diff[~risk].max() <= PIX_TOL, f"max pixel err {diff[~risk].max()}"
-    assert diff.max() <= 2.0 / 255.0 + PIX_TOL
+    exact, cond = O.rasterize_forward_f64(gpu["u"], oa)
+    gpu_err = np.abs(gpu["out"].astype(np.float64) - exact).max(axis=2)
+    tol = PIX_TOL + 3.0 * EPS32 * cond
+    over = (gpu_err > tol) & ~risk
+    assert not over.any(), (f"{int(over.sum())} pixels: max |gpu - f64| {gpu_err[over].max()} (allowance {tol[over].min()}); "
+                            f"max |gpu - f32 restatement| {diff[~risk].max()}")
+    print(f"pixels: max |gpu - f64| {gpu_err[~risk].max():.2e}, median allowance {np.median(tol):.2e}, "
+          f"pixels whose allowance exceeds 2e-4: {int((tol > 2e-4).sum())} of {tol.size}")
+    assert diff.max() <= 2.0 / 255.0 + 2.0 * tol.max()
+    gpu["pixel_allowance_max"] = float(tol.max())  # the end-to-end gradient check scales with the forward's conditioning
     fi = _np_u32(aux.final_index)
     differ = (fi != oa["final_index"]) & ~risk
     if saturation_flip_frac == 0.0:
@@ -270,7 +285,8 @@ def _assert_grad_parity(gpu, orc, tag=""):
         # end to end (oracle forward state): loose, the amplification is inherent to the reference's formulation
         e2e = orc["grads"][name].astype(np.float64).reshape(a.shape)
         s2 = np.abs(e2e).max() + 1e-30
-        assert (np.abs(a - e2e) <= 2e-4 * np.abs(e2e) + 1e-3 * s2).all(), f"{name} end-to-end"
+        slack = max(1.0, gpu.get("pixel_allowance_max", PIX_TOL) / PIX_TOL)  # ill-conditioned forward: its pixels move too
+        assert (np.abs(a - e2e) <= 2e-4 * np.abs(e2e) + 1e-3 * slack * s2).all(), f"{name} end-to-end"
         # dense and exactly zero for non-visible splats
         vis = np.zeros(a.shape[0], bool)
         vis[orc["aux"]["global_from_compact_gid"][:V]] = True

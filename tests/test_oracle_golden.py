@@ -30,6 +30,11 @@ def test_reference_golden(case):
     chk("xys", aux["projected_splats"][:V, 0:2], d["xys"][perm], 1e-4, 1e-10)
     chk("conics", aux["projected_splats"][:V, 2:5], d["conics"][perm], 1e-4, 5e-7)
     chk("out_img", out[..., :3], d["out_img"], 1e-4, 1e-9)
+    # the f64 evaluation of the same walk (arbiter of the GPU pixel tolerance) agrees with the pinned f32 result
+    exact, cond = O.rasterize_forward_f64(u, aux)
+    assert np.isfinite(cond).all() and cond.max() < 1e4  # well-conditioned fixture
+    assert np.abs(exact - out.astype(np.float64)).max() < 2e-6
+    chk("out_img_f64", exact[..., :3].astype(np.float32), d["out_img"], 1e-4, 1e-9)
 
     # loss = mean((rgb - crab)^2)  (render.rs:786-789)
     v_out = np.zeros((h, w, 4), np.float32)
