@@ -1,12 +1,12 @@
 """Randomised parity sweep on the GPU box (development aid, not part of the suite): small random clouds, image sizes,
 SH degrees and spreads through the same GPU-vs-checker assertions as tests/test_gpu_render.py
-(bit-exact integer stages, pixels, arbiter-based gradient tolerance).  usage: python tools/fuzz_parity.py [cases] [seed]"""
+(bit-exact integer stages, pixels, arbiter-based gradient tolerance).  usage: python tests/fuzz_parity.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402

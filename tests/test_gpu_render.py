@@ -201,7 +201,7 @@ def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0):
     # splat tens of thousands of pixels wide, far off-screen) any f32 evaluation of sigma is off by up to ~3 eps32 of
     # the CANCELLING terms — with or without the fused multiply-adds the reference leaves to its shader compiler — so
     # the allowance grows with the f64 pass's first-order sensitivity `cond` to exactly that (found by
-    # tools/fuzz_parity.py with the camera inside a dense cloud: the GPU and the f32 restatement are equally far from
+    # tests/fuzz_parity.py with the camera inside a dense cloud: the GPU and the f32 restatement are equally far from
     # f64 there, 1.2e-4 / 1.5e-4 at the 99th percentile, and 6e-4 from each other; on the bench scenes cond is small
     # and this is the plain 1e-4 test).
     risk = oa["flip_risk"].astype(bool)
