@@ -25,9 +25,10 @@ def main():
         deg = int(rng.integers(0, 5))
         mult = float(rng.choice([0.0005, 0.002, 0.01, 0.05, 0.3, 1.0]))
         seed = int(rng.integers(0, 1000))
-        tag = f"case {i}: n={n} {w}x{h} deg={deg} mult={mult} seed={seed}"
+        cap = int(rng.choice([3_000_000, 3_000_000, 20_000, 700]))  # small capacities: truncated lists, overflow flag
+        tag = f"case {i}: n={n} {w}x{h} deg={deg} mult={mult} seed={seed} cap={cap}"
         cloud = H.synthetic_cloud(n, deg, seed=seed, mean_mult=mult)
-        gpu, orc = T._run_pair(dev, cloud, w, h, deg, max_intersects=3_000_000)
+        gpu, orc = T._run_pair(dev, cloud, w, h, deg, max_intersects=cap)
         V, I = T._assert_forward_parity(gpu, orc, w, h)
         T._assert_grad_parity(gpu, orc, tag)
         print(tag, "V", V, "I", I, "ok", flush=True)

@@ -205,7 +205,11 @@ def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0):
     # f64 there, 1.2e-4 / 1.5e-4 at the 99th percentile, and 6e-4 from each other; on the bench scenes cond is small
     # and this is the plain 1e-4 test).
     risk = oa["flip_risk"].astype(bool)
-    assert risk.mean() < 2e-3 or risk.sum() <= 16  # the fraction means little on a thumbnail-sized image
+    # how many pixels may sit inside a guard band: each of a pixel's entries lands within 1e-5 relative of a threshold
+    # with probability ~2e-5, so the bound grows with the depth of the lists (it means little on a thumbnail either)
+    lens = (oa["tile_bins"][..., 1].astype(np.int64) - oa["tile_bins"][..., 0].astype(np.int64)).reshape(-1)
+    depth = float(lens[lens > 0].mean()) if (lens > 0).any() else 0.0
+    assert risk.mean() < 2e-3 + 2e-5 * depth or risk.sum() <= 16, (float(risk.mean()), depth)
     diff = np.abs(gpu["out"] - orc["out"]).max(axis=2)
     exact, cond = O.rasterize_forward_f64(gpu["u"], oa)
     gpu_err = np.abs(gpu["out"].astype(np.float64) - exact).max(axis=2)
