@@ -719,6 +719,58 @@ def test_view_records_round_trip(dev, deg):
     assert not bool(grads2["v_means"][dropped].any())  # records whose gid is out of range are ignored, entries re-validated
 
 
+def test_view_records_many_views(dev):
+    """Five views of one cloud on one GPU, their records laid out as the all-gather would leave them: the HIP reduction
+    (dense form) adds a splat's records in view order exactly like the torch restatement (bit for bit for the per-splat
+    vectors, v_sh to rounding), twice in a row on the same index buffer (entries consumed by the first call are gone,
+    the second rebuilds them), and splats no view sees get exact zeros."""
+    import torch
+
+    import brush_amd
+    from brush_amd import dist as BD
+    from brush_amd import render as R
+
+    n, w, h, deg, W = 60000, 320, 240, 3, 5
+    C = (deg + 1) ** 2
+    cloud = H.synthetic_cloud(n, deg, seed=12, mean_mult=0.01)
+    p = {k: _t(v, dev) for k, v in cloud.items()}
+    v_out = torch.randn((h, w, 4), device=dev) / (h * w)
+    base = H.reference_test_camera(w, h)
+    views, seen = [], torch.zeros(n, dtype=torch.bool, device=dev)
+    for r in range(W):
+        ang = 0.3 * r
+        rot = [0.0, math.sin(ang / 2), 0.0, math.cos(ang / 2)]
+        pos = [-4.0 * math.sin(ang), 0.0, -4.0 * math.cos(ang)]
+        cam = brush_amd.Camera(pos, rot, base["fov_x"], base["fov_y"], base["center_uv"])
+        out, aux, u = R._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"], False,
+                                      2_000_000)
+        x = BD.ViewExchange(n, C, dev)
+        x.begin(aux)
+        x.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, v_out)
+        recs = x.gather()
+        V = aux.read_num_visible()
+        assert V > 500
+        seen[aux.global_from_compact_gid[:V].long()] = True
+        views.append((recs[0, :V].clone(), x.metas.clone()))
+    rows = max(v[0].shape[0] for v in views)
+    x = BD.ViewExchange(n, C, dev)
+    x.world = W
+    x.metas = torch.cat([v[1] for v in views], 0).contiguous()
+    x._ensure_capacity(rows)
+    x._rows = rows
+    g = x.gathered[:W * rows * 16].view(W, rows, 16)
+    for i, v in enumerate(views):
+        g[i, :v[0].shape[0]] = v[0]
+    ref = BD.reduce_view_records_torch(g, x.metas[:, 0], x.metas[:, 1:4].contiguous().view(torch.float32), p["means"], n, C)
+    for rep in range(2):
+        grads, _ = x.reduce_dense(p["means"])
+        for name in ("v_means", "v_scales", "v_quats", "v_opac"):
+            assert torch.equal(grads[name], ref[name]), (name, rep)
+        assert float((grads["v_sh"] - ref["v_sh"]).abs().max()) <= 4e-6 * float(ref["v_sh"].abs().max())
+        assert not bool(grads["v_sh"][~seen].any()) and not bool(grads["v_quats"][~seen].any())
+        assert bool(grads["v_means"][seen].any())
+
+
 def test_training_steps_reduce_loss(dev):
     """the reference's step (L1 + 0.2*SSIM, five Adam groups, SH lerp) drives
     the op end to end; fitting a render of perturbed parameters must reduce the loss."""
