@@ -5,9 +5,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbrush_hip.so")
+# BRUSH_HIP_LIB: load another build of the same ABI (tests/test_gpu_gate.py loads the error-injected twin); it must
+# exist just like the default one — there is no fallback of any kind.
+LIB_PATH = os.environ.get("BRUSH_HIP_LIB") or os.path.join(_HERE, "lib", "libbrush_hip.so")
 
 BRUSH_OK = 0
+AUX_DETERMINISTIC = 1  # BrushAux.flags: BRUSH_AUX_DETERMINISTIC
 UNIFORM_WORDS = 28
 NUM_VISIBLE_WORD = 25
 TILE_WIDTH = 16
@@ -45,6 +48,7 @@ class BrushAux(C.Structure):
         ("overflow", C.c_void_p),
         ("max_intersects", C.c_uint32),
         ("isect_unsorted_pos", C.c_void_p),  # deterministic mode only (NULL otherwise)
+        ("flags", C.c_uint32),               # AUX_* bits, per call
     ]
 
 
@@ -87,6 +91,8 @@ _SYMBOLS = [
      [C.POINTER(BrushUniforms), _P, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(BrushAux), _P,
       C.c_size_t, _P]),
     ("brush_deterministic", C.c_int, []),
+    ("brush_bwd_workspace_size_flags", C.c_int,
+     [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
     ("brush_bwd_workspace_size", C.c_int,
      [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
     ("brush_bwd_workspace_size_ex", C.c_int,

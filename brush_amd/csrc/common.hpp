@@ -20,11 +20,10 @@ constexpr uint32_t kNumVisibleWord = 25;                // render.rs:145-149
 constexpr uint32_t kCompactStride = 16;
 constexpr uint32_t kCompactVec = kCompactStride / 4;  // float4 words per row
 
-// BRUSH_DETERMINISTIC=1 (read once per process): the compositing backward writes one gradient row per
-// intersection instead of float atomics and the rows are summed per splat in a fixed order, so gradients are
-// bitwise reproducible run to run; the forward then also records where every sorted intersection sat before
-// the tile sort (BrushAux::isect_unsorted_pos).
-bool deterministic_mode();
+// Deterministic mode (BrushAux::flags & BRUSH_AUX_DETERMINISTIC, chosen per call): the compositing backward writes
+// one gradient row per intersection instead of float atomics and the rows are summed per splat in a fixed order, so
+// gradients are bitwise reproducible run to run; the forward then also records where every sorted intersection sat
+// before the tile sort (BrushAux::isect_unsorted_pos).
 
 // Records the failing hipError_t for brush_last_hip_error().
 void set_last_hip_error(int e);
@@ -81,8 +80,10 @@ hipError_t scan_launch(const uint32_t *in, uint32_t *out, uint32_t n, const uint
 // radix_sort.hip
 size_t sort_workspace_bytes(uint32_t max_n);
 // vals_in == nullptr sorts the positions 0..n-1 themselves (argsort proper).
+// edges != nullptr (zero-initialised [edge_keys][2], keys < edge_keys): the last pass also records the run of every
+// key value k in the sorted output as edges[2k] = ~start, edges[2k+1] = end (both 0 for a key that does not occur).
 hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
                        uint32_t *vals_out, const uint32_t *d_n, uint32_t max_n, uint32_t bits,
-                       void *ws, hipStream_t s);
+                       void *ws, hipStream_t s, uint32_t *edges = nullptr, uint32_t edge_keys = 0);
 
 }  // namespace brush

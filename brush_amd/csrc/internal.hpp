@@ -22,7 +22,8 @@ hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, con
                                uint32_t num_tiles, const float *means, const float *log_scales,
                                const float *quats, const float *sh, const float *raw_opac, float *proj_global,
                                uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
-                               uint32_t *gids, const WalkWs &walk, hipStream_t s);
+                               uint32_t *gids, uint32_t *bin_edges /* [num_tiles][2], zeroed here */,
+                               const WalkWs &walk, hipStream_t s);
 hipError_t launch_project_visible(const ViewParams &vp, const float *proj_global, const uint32_t *num_visible,
                                   uint32_t *global_from_compact, uint32_t *compact_from_global, float *projected,
                                   uint32_t *tiles_hit, const WalkWs &walk, hipStream_t s);
@@ -35,8 +36,10 @@ hipError_t launch_tile_bin_edges(const uint32_t *sorted_tile_ids, const uint32_t
                                  const uint32_t *gid_unsorted, uint32_t *gid_sorted, hipStream_t s);
 
 // rasterize.hip
+// bin_edges != nullptr: the tile sort's last pass left (~start, end) per tile there (sort_launch: edges) instead of a
+// GetTileBinEdges launch; the kernel decodes them and writes tile_bins (every tile) for the aux / the backward.
 hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
-                            const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
+                            const uint32_t *compact_gid_from_isect, uint32_t *tile_bins, const uint32_t *bin_edges,
                             const float *projected, int raster_u32, uint32_t u32_pitch, void *out_img,
                             uint32_t *final_index, hipStream_t s);
 hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,

@@ -162,11 +162,13 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
                                                uint32_t n, uint32_t shift, uint32_t mask,
                                                const uint32_t *__restrict__ counts,
                                                const uint32_t *__restrict__ totals, uint32_t max_tiles,
-                                               LDS &L) {
+                                               uint32_t *__restrict__ edges, uint32_t edge_keys, LDS &L) {
     static_assert(!FUSED || THREADS == kSortThreads, "the fused table sums assume 4 quarters of 256 threads");
     constexpr uint32_t kTileKeys = THREADS * ITEMS;
     constexpr uint32_t kWaves = THREADS / kWave;
-    constexpr bool kReorder = ITEMS > 2;  // small sorts: the scatter is a few hundred KB, not worth two barriers
+    // small sorts: the scatter is a few hundred KB, not worth two barriers — unless the pass also finds the run
+    // edges (below), which needs every key's neighbours in output order
+    const bool reorder = ITEMS > 2 || edges != nullptr;
     const uint32_t tile = blockIdx.x;
     const uint32_t wid = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
@@ -264,7 +266,7 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
         L.tile_start[threadIdx.x] = run_start;
     }
     __syncthreads();  // C
-    if (!kReorder) {
+    if (!reorder) {
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
             const uint32_t idx = chunk + i * kWave + lane;
@@ -299,9 +301,22 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
         if (lp < tile_n) {
             const uint32_t k = L.keys[lp];
             const uint32_t digit = (k >> shift) & mask;
-            const uint32_t pos = L.digit_base[digit] + (lp - L.tile_start[digit]);
+            const uint32_t ts = L.tile_start[digit];
+            const uint32_t pos = L.digit_base[digit] + (lp - ts);
             keys_out[pos] = k;
             vals_out[pos] = L.vals[lp];
+            // LAST pass only (edges != nullptr): the keys are in their final order, so the run of equal keys around
+            // `pos` is a bin of the caller (GetTileBinEdges, get_tile_bin_edges.wgsl:15-42, without its launch).  A key
+            // that differs from its predecessor / successor inside this workgroup's run of the digit proposes
+            // [pos, pos + 1) as (start, end); so do the first and the last key of the run, whose outer neighbours belong
+            // to other workgroups.  edges[2k] = max ~start, edges[2k+1] = max end over all proposals (zero-initialised
+            // by the caller): proposals from the inside of a bin lose against the true edges.
+            if (edges && k < edge_keys) {
+                const bool first = lp == ts;
+                const bool last = lp + 1 == tile_n || ((L.keys[lp + 1] >> shift) & mask) != digit;
+                if (first || L.keys[lp - 1] != k) atomicMax(&edges[2 * k], ~pos);
+                if (last || L.keys[lp + 1] != k) atomicMax(&edges[2 * k + 1], pos + 1u);
+            }
         }
     }
 }
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ d_n,
     uint32_t max_n, uint32_t shift, uint32_t mask, const uint32_t *__restrict__ counts,
-    const uint32_t *__restrict__ totals, uint32_t max_tiles) {
+    const uint32_t *__restrict__ totals, uint32_t max_tiles, uint32_t *__restrict__ edges, uint32_t edge_keys) {
     const uint32_t n = min(*d_n, max_n);
     const uint32_t items = sort_items(n);
     if ((uint64_t)blockIdx.x * kSortThreads * items >= n) return;
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
     DownLds &L = *reinterpret_cast<DownLds *>(lds_raw);
 #define BRUSH_DOWN(K)                                                                                             \
     downsweep_body<FUSED, K, kSortThreads>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, counts, totals, \
-                                           max_tiles, L)
+                                           max_tiles, edges, edge_keys, L)
     switch (items) {  // block-uniform
         case 1: BRUSH_DOWN(1); break;
         case 2: BRUSH_DOWN(2); break;
@@ -335,13 +350,13 @@ __global__ __launch_bounds__(kBigThreads) void k_sort_downsweep_big(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ d_n,
     uint32_t max_n, uint32_t shift, uint32_t mask, const uint32_t *__restrict__ counts,
-    const uint32_t *__restrict__ totals, uint32_t max_tiles) {
+    const uint32_t *__restrict__ totals, uint32_t max_tiles, uint32_t *__restrict__ edges, uint32_t edge_keys) {
     const uint32_t n = min(*d_n, max_n);
     if ((uint64_t)blockIdx.x * kBigTileKeys >= n) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     DownLdsBig &L = *reinterpret_cast<DownLdsBig *>(lds_raw);
     downsweep_body<false, kBigTileKeys / kBigThreads, kBigThreads>(keys_in, vals_in, keys_out, vals_out, n, shift,
-                                                                   mask, counts, totals, max_tiles, L);
+                                                                   mask, counts, totals, max_tiles, edges, edge_keys, L);
 }
 
 __global__ void k_sort_copy(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
@@ -390,8 +405,9 @@ size_t sort_workspace_bytes(uint32_t max_n) { return carve_sort(nullptr, max_n).
 
 hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
                        uint32_t *vals_out, const uint32_t *d_n, uint32_t max_n, uint32_t bits, void *ws,
-                       hipStream_t s) {
+                       hipStream_t s, uint32_t *edges, uint32_t edge_keys) {
     if (max_n == 0) return hipSuccess;
+    if (edges && bits == 0) return hipErrorInvalidValue;  // the edges come out of the last pass
     const SortWs w = carve_sort(ws, max_n);
     const uint32_t total_bits = 4u * ((bits + 3u) / 4u);  // brush-sort/src/lib.rs:58
     const uint32_t passes = (total_bits + 7u) / 8u;
@@ -411,17 +427,20 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
         const bool to_out = ((passes - 1 - p) % 2u) == 0;
         uint32_t *dst_k = to_out ? keys_out : w.tmp_keys;
         uint32_t *dst_v = to_out ? vals_out : w.tmp_vals;
+        uint32_t *pass_edges = p + 1 == passes ? edges : nullptr;
         if (fused) {
             hipLaunchKernelGGL(k_sort_upsweep<true>, dim3(w.max_tiles), dim3(kSortThreads), 0, s, src_k, d_n, max_n,
                                shift, mask, w.counts, w.max_tiles);
             hipLaunchKernelGGL(k_sort_downsweep<true>, dim3(w.max_tiles), dim3(kSortThreads), sizeof(DownLds), s, src_k,
-                               src_v, dst_k, dst_v, d_n, max_n, shift, mask, w.counts, w.totals, w.max_tiles);
+                               src_v, dst_k, dst_v, d_n, max_n, shift, mask, w.counts, w.totals, w.max_tiles, pass_edges,
+                               edge_keys);
         } else {
             hipLaunchKernelGGL(k_sort_upsweep<false>, dim3(w.max_tiles), dim3(kSortThreads), 0, s, src_k, d_n, max_n,
                                shift, mask, w.counts, w.max_tiles);
             hipLaunchKernelGGL(k_sort_scan, dim3(kRadix), dim3(256), 0, s, w.counts, d_n, max_n, w.max_tiles, w.totals);
             hipLaunchKernelGGL(k_sort_downsweep_big, dim3(w.max_tiles), dim3(kBigThreads), sizeof(DownLdsBig), s,
-                               src_k, src_v, dst_k, dst_v, d_n, max_n, shift, mask, w.counts, w.totals, w.max_tiles);
+                               src_k, src_v, dst_k, dst_v, d_n, max_n, shift, mask, w.counts, w.totals, w.max_tiles,
+                               pass_edges, edge_keys);
         }
         src_k = dst_k;
         src_v = dst_v;

@@ -111,8 +111,8 @@ struct QuadRec {
 template <bool RASTER_U32>
 __global__ __launch_bounds__(kRasterThreads) void k_rasterize_quad(
     uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles, const uint32_t *__restrict__ gid_from_isect,
-    const uint32_t *__restrict__ tile_bins, const float *__restrict__ projected, void *__restrict__ out_img,
-    uint32_t *__restrict__ final_index, uint32_t u32_pitch) {
+    uint32_t *__restrict__ tile_bins, const uint32_t *__restrict__ bin_edges, const float *__restrict__ projected,
+    void *__restrict__ out_img, uint32_t *__restrict__ final_index, uint32_t u32_pitch) {
     __shared__ QuadRec lds_all[kTilesPerBlock][kBatch];
     const uint32_t q = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     QuadRec *lds = lds_all[q];
@@ -132,7 +132,21 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_quad(
     uint32_t walked = 0;
     float T = 1.0f, cr = 0.0f, cg = 0.0f, cb_ = 0.0f;
     uint32_t fin = 0;
-    const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
+    uint32_t r0, r1;
+    if (bin_edges) {
+        // GetTileBinEdges (get_tile_bin_edges.wgsl:15-42) without its launch: the tile sort's last pass left
+        // (max ~start, max end) of this tile's run; (0, 0) = the tile id does not occur.  Quadrant 0 (always inside
+        // the frame) publishes the decoded pair for the aux and the backward.
+        const uint32_t ns = bin_edges[tile_id * 2];
+        r1 = bin_edges[tile_id * 2 + 1];
+        r0 = r1 ? ~ns : 0u;
+        if (q == 0u && lane == 0u) {
+            tile_bins[tile_id * 2] = r0;
+            tile_bins[tile_id * 2 + 1] = r1;
+        }
+    } else {
+        r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
+    }
     for (uint32_t batch_start = r0; batch_start < r1 && live != 0ull; batch_start += kBatch) {
         const uint32_t remaining = min(kBatch, r1 - batch_start);
         bool hit = false;
@@ -418,7 +432,11 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
                     // v_sigma = -opac vis v_alpha; the factors that are the same for every pixel (-opac, the conic
                     // in gx / gy, the 1/2 of the conic terms) are applied once per record at the flush:
                     //   g0 = sum vva dx, g1 = sum vva dy, g2..4 = sum vva (dx dx, dx dy, dy dy), g8 = sum vva
+#ifdef BRUSH_INJECT_VVA_ULPS  // test-only build (libbrush_hip_inject.so): a one-signed error of that many eps32 per term
+                    const float vva = fmaf(fabsf(vis * v_alpha), BRUSH_INJECT_VVA_ULPS * 5.9604645e-8f, vis * v_alpha);
+#else
                     const float vva = vis * v_alpha;
+#endif
                     const float wx = vva * dx, wy = vva * dy;
                     g[0] += wx;
                     g[1] += wy;
@@ -506,7 +524,7 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
 }  // namespace
 
 hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
-                            const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
+                            const uint32_t *compact_gid_from_isect, uint32_t *tile_bins, const uint32_t *bin_edges,
                             const float *projected, int raster_u32, uint32_t u32_pitch, void *out_img,
                             uint32_t *final_index, hipStream_t s) {
     const uint32_t tiles = tbx * tby;
@@ -515,10 +533,10 @@ hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
     const dim3 grid(ceil_div(tiles, 8u) * 8u), block(kRasterThreads);
     if (raster_u32)
         hipLaunchKernelGGL(k_rasterize_quad<true>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
-                           tile_bins, projected, out_img, final_index, u32_pitch);
+                           tile_bins, bin_edges, projected, out_img, final_index, u32_pitch);
     else
         hipLaunchKernelGGL(k_rasterize_quad<false>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
-                           tile_bins, projected, out_img, final_index, u32_pitch);
+                           tile_bins, bin_edges, projected, out_img, final_index, u32_pitch);
     return hipGetLastError();
 }
 

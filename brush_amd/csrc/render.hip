@@ -16,14 +16,6 @@ namespace brush {
 static thread_local int g_last_hip_error = 0;
 void set_last_hip_error(int e) { g_last_hip_error = e; }
 
-bool deterministic_mode() {
-    static const bool on = [] {
-        const char *e = getenv("BRUSH_DETERMINISTIC");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-
 }  // namespace brush
 
 // Opt-in stage timing: events [0] = forward start, [1 + stage] = end of forward stage,
@@ -65,13 +57,14 @@ struct FwdWs {
     uint32_t *tile_unsorted; // [cap]
     uint32_t *gid_unsorted;  // [cap]
     uint32_t *tile_sorted;   // [cap]
+    uint32_t *bin_edges;     // [tiles][2] (~start, end) accumulated by the tile sort's last pass
     void *scan_ws;
     void *sort_ws;           // sized for max(N, cap)
     WalkWs walk;             // (splat, chunk) queue of the tile walks
     size_t bytes;
 };
 
-FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap) {
+FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap, uint32_t num_tiles) {
     FwdWs f;
     Carver c(ws);
     const size_t nn = n ? n : 1, cc = cap ? cap : 1;
@@ -85,6 +78,7 @@ FwdWs carve_fwd(void *ws, uint32_t n, uint32_t cap) {
     f.tile_unsorted = c.take<uint32_t>(cc);
     f.gid_unsorted = c.take<uint32_t>(cc);
     f.tile_sorted = c.take<uint32_t>(cc);
+    f.bin_edges = c.take<uint32_t>((size_t)(num_tiles ? num_tiles : 1) * 2);
     f.scan_ws = c.take<char>(scan_workspace_bytes(n));
     f.sort_ws = c.take<char>(sort_workspace_bytes(n > cap ? n : cap));
     f.walk.capacity = (uint32_t)nn;
@@ -105,13 +99,13 @@ struct BwdWs {
     size_t bytes;
 };
 
-BwdWs carve_bwd(void *ws, uint32_t n, uint32_t cap) {
+BwdWs carve_bwd(void *ws, uint32_t n, uint32_t cap, bool det) {
     BwdWs b;
     Carver c(ws);
     const size_t nn = n ? n : 1;
     b.v_compact = c.take<float>(nn * kCompactStride);
     b.rows = b.partials = nullptr;
-    if (deterministic_mode()) {
+    if (det) {
         const size_t cc = cap ? cap : 1;
         b.rows = c.take<float>(cc * kCompactStride);
         b.partials = c.take<float>((size_t)ceil_div((uint32_t)cc, kWave) * 2 * kCompactStride);
@@ -120,8 +114,11 @@ BwdWs carve_bwd(void *ws, uint32_t n, uint32_t cap) {
     return b;
 }
 
+inline bool aux_det(const BrushAux &a) { return (a.flags & BRUSH_AUX_DETERMINISTIC) != 0; }
+
 bool aux_ok(const BrushAux *a, bool need_final_index) {
-    if (a && deterministic_mode() && !a->isect_unsorted_pos) return false;
+    if (a && (a->flags & ~BRUSH_AUX_DETERMINISTIC) != 0) return false;  // unknown flag bits
+    if (a && aux_det(*a) && !a->isect_unsorted_pos) return false;
     return a && a->projected_splats && a->uniforms_buffer && a->num_intersections && a->num_visible &&
            (a->final_index || !need_final_index) && a->cum_tiles_hit && a->tile_bins &&
            a->compact_gid_from_isect && a->global_from_compact_gid && a->compact_from_global_gid && a->overflow;
@@ -164,22 +161,29 @@ extern "C" uint32_t brush_default_max_intersects(uint32_t n, uint32_t w, uint32_
 
 extern "C" int brush_fwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
                                         uint32_t max_intersects, size_t *bytes) {
-    (void)w;
-    (void)h;
     if (!bytes || sh_degree > 4) return BRUSH_ERR_INVALID_ARG;
-    *bytes = carve_fwd(nullptr, n, max_intersects).bytes;
+    *bytes = carve_fwd(nullptr, n, max_intersects, ceil_div(w, kTileWidth) * ceil_div(h, kTileWidth)).bytes;
     return BRUSH_OK;
 }
 
-extern "C" int brush_deterministic(void) { return deterministic_mode() ? 1 : 0; }
+// Host-side default only (not cached, not read by any render entry point): see brush_hip.h.
+extern "C" int brush_deterministic(void) {
+    const char *e = getenv("BRUSH_DETERMINISTIC");
+    return (e && e[0] == '1') ? 1 : 0;
+}
+
+extern "C" int brush_bwd_workspace_size_flags(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
+                                              uint32_t max_intersects, uint32_t flags, size_t *bytes) {
+    (void)w;
+    (void)h;
+    if (!bytes || sh_degree > 4 || (flags & ~BRUSH_AUX_DETERMINISTIC) != 0) return BRUSH_ERR_INVALID_ARG;
+    *bytes = carve_bwd(nullptr, n, max_intersects, (flags & BRUSH_AUX_DETERMINISTIC) != 0).bytes;
+    return BRUSH_OK;
+}
 
 extern "C" int brush_bwd_workspace_size_ex(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
                                            uint32_t max_intersects, size_t *bytes) {
-    (void)w;
-    (void)h;
-    if (!bytes || sh_degree > 4) return BRUSH_ERR_INVALID_ARG;
-    *bytes = carve_bwd(nullptr, n, max_intersects).bytes;
-    return BRUSH_OK;
+    return brush_bwd_workspace_size_flags(n, w, h, sh_degree, max_intersects, 0u, bytes);
 }
 
 extern "C" int brush_bwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree, size_t *bytes) {
@@ -196,7 +200,7 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
     const BrushAux &aux = *h_aux;
     const uint32_t cap = aux.max_intersects;
     if (cap == 0) return BRUSH_ERR_INVALID_ARG;
-    const FwdWs ws = carve_fwd(workspace, n, cap);
+    const FwdWs ws = carve_fwd(workspace, n, cap, h_uniforms->tile_bounds[0] * h_uniforms->tile_bounds[1]);
     if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
     hipStream_t s = static_cast<hipStream_t>(stream);
 
@@ -214,7 +218,7 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
     // (render.rs:102-142)
     BRUSH_HIP_CHECK(launch_project_cull(vp, u, aux, num_tiles, means, log_scales, quats, sh_coeffs, raw_opacity,
                                         ws.proj_global, ws.key_all, ws.block_counts, ws.pre_keys, ws.pre_gids,
-                                        ws.walk, s));
+                                        ws.bin_edges, ws.walk, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_CULL);
     // DepthSort: keys = f32 depth bits, all 32 bits (render.rs:151-156)
     BRUSH_HIP_CHECK(sort_launch(ws.pre_keys, ws.pre_gids, ws.sorted_keys, aux.global_from_compact_gid,
@@ -237,21 +241,22 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
     uint32_t bits = 0;
     while (bits < 32 && (num_tiles >> bits) != 0) bits++;
     // Deterministic mode: the sort carries the pre-sort positions (aux.isect_unsorted_pos) and the gids follow by
-    // a gather in the bin-edge kernel.
-    const bool det = deterministic_mode();
+    // a gather in the bin-edge kernel.  Default mode: GetTileBinEdges (render.rs:239-262) has no launch of its own —
+    // the sort's last pass sees every key next to its neighbours in final order and records the edges of the runs
+    // (ws.bin_edges), the compositing kernel decodes them and writes aux.tile_bins.
+    const bool det = aux_det(aux);
     BRUSH_HIP_CHECK(sort_launch(ws.tile_unsorted, det ? nullptr : ws.gid_unsorted, ws.tile_sorted,
                                 det ? aux.isect_unsorted_pos : aux.compact_gid_from_isect, aux.num_intersections, cap,
-                                bits, ws.sort_ws, s));
+                                bits, ws.sort_ws, s, det ? nullptr : ws.bin_edges, num_tiles));
     mark_fwd(s, 1 + BRUSH_STAGE_TILE_SORT);
-    // GetTileBinEdges (render.rs:239-262)
-    BRUSH_HIP_CHECK(launch_tile_bin_edges(ws.tile_sorted, aux.num_intersections, cap, aux.tile_bins,
-                                          det ? aux.isect_unsorted_pos : nullptr, ws.gid_unsorted,
-                                          aux.compact_gid_from_isect, s));
+    if (det)
+        BRUSH_HIP_CHECK(launch_tile_bin_edges(ws.tile_sorted, aux.num_intersections, cap, aux.tile_bins,
+                                              aux.isect_unsorted_pos, ws.gid_unsorted, aux.compact_gid_from_isect, s));
     mark_fwd(s, 1 + BRUSH_STAGE_TILE_BINS);
     // Rasterize (render.rs:267-307)
     BRUSH_HIP_CHECK(launch_rasterize(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
-                                     aux.projected_splats, raster_u32, u32_pitch ? u32_pitch : w, out_img,
-                                     aux.final_index, s));
+                                     det ? nullptr : ws.bin_edges, aux.projected_splats, raster_u32,
+                                     u32_pitch ? u32_pitch : w, out_img, aux.final_index, s));
     mark_fwd(s, 1 + BRUSH_STAGE_RASTERIZE);
     return BRUSH_OK;
 }
@@ -316,7 +321,7 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
     if (n > 0 && (!means || !log_scales || !quats || !raw_opacity || !v_xy)) return BRUSH_ERR_INVALID_ARG;
     if (n > 0 && !adam && (!v_means || !v_scales || !v_quats || !v_sh || !v_opac)) return BRUSH_ERR_INVALID_ARG;
     const BrushAux &aux = *h_aux;
-    const BwdWs ws = carve_bwd(workspace, n, aux.max_intersects);
+    const BwdWs ws = carve_bwd(workspace, n, aux.max_intersects, aux_det(aux));
     if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
     hipStream_t s = static_cast<hipStream_t>(stream);
 
@@ -403,7 +408,7 @@ extern "C" int brush_render_backward_records(const BrushUniforms *h_uniforms, co
         return BRUSH_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(records) & 15) != 0) return BRUSH_ERR_INVALID_ARG;
     const BrushAux &aux = *h_aux;
-    const BwdWs ws = carve_bwd(workspace, n, aux.max_intersects);
+    const BwdWs ws = carve_bwd(workspace, n, aux.max_intersects, aux_det(aux));
     if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     BrushUniforms u = *h_uniforms;

@@ -242,8 +242,8 @@ class ViewExchange:
         n = means.shape[0]
         w, h = int(u.img_size[0]), int(u.img_size[1])
         nbytes = C.c_size_t()
-        _lib.check(l.brush_bwd_workspace_size_ex(n, w, h, int(u.sh_degree), int(aux.max_intersects), C.byref(nbytes)),
-                   "brush_bwd_workspace_size_ex")
+        _lib.check(l.brush_bwd_workspace_size_flags(n, w, h, int(u.sh_degree), int(aux.max_intersects), int(aux.flags),
+                                                    C.byref(nbytes)), "brush_bwd_workspace_size_flags")
         if getattr(self, "_ws", None) is None or self._ws.numel() < nbytes.value:
             self._ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=self.device)
         s = aux._as_struct()
@@ -280,15 +280,18 @@ class ViewExchange:
             out.copy_(part)
         return out.view(self.world, rows, _REC)
 
-    def _reduce_common(self):
+    def _reduce_common(self, n: int):
         import ctypes as C
 
         from . import _lib
 
         nbytes = C.c_size_t()
-        _lib.check(_lib.lib().brush_view_index_size(self.n, self.world, C.byref(nbytes)), "brush_view_index_size")
-        if self.index is None or self.index.numel() < nbytes.value:
+        _lib.check(_lib.lib().brush_view_index_size(n, self.world, C.byref(nbytes)), "brush_view_index_size")
+        if self.index is None or n != self.n or self.index.numel() < nbytes.value:
+            # The splat count follows the PARAMETERS of the call, not the count this object was built with: refinement
+            # (train.rs:395-579) clones, splits and prunes between steps, and the index is laid out [view][n].
             # all-ones = "no row": the reduction clears what it consumes, so the buffer never holds stale entries
+            self.n = int(n)
             self.index = torch.full((nbytes.value,), 0xFF, dtype=torch.uint8, device=self.device)
         recs = self.gathered[:self.world * self._rows * _REC]
         view_rows = self.metas[:, 0].contiguous()
@@ -300,11 +303,11 @@ class ViewExchange:
         v_xy of the block is left untouched (per-view statistic)."""
         from . import _lib
 
-        n, ncoef = self.n, self.ncoef
+        n, ncoef = int(means.shape[0]), self.ncoef
         layout, total = grad_block_layout(n, ncoef)
         if block is None:
             block = torch.empty(max(total, 1), dtype=torch.float32, device=self.device)
-        recs, view_rows, campos, ibytes = self._reduce_common()
+        recs, view_rows, campos, ibytes = self._reduce_common(n)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().brush_reduce_view_records(
                 recs.data_ptr(), self.world, self._rows, view_rows.data_ptr(), campos.data_ptr(), means.data_ptr(), n,
@@ -328,13 +331,15 @@ class ViewExchange:
 
         from . import _lib
 
-        recs, view_rows, campos, ibytes = self._reduce_common()
+        n = int(means.shape[0])
+        assert moment1.numel() == n * (11 + 3 * self.ncoef) == moment2.numel(), "moments are laid out for another splat count"
+        recs, view_rows, campos, ibytes = self._reduce_common(n)
         ptr = lambda t: None if t is None else t.data_ptr()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().brush_reduce_view_records_adam(
                 recs.data_ptr(), self.world, self._rows, view_rows.data_ptr(), campos.data_ptr(), C.byref(cfg),
                 int(img_size[0]), int(img_size[1]), means.data_ptr(), log_scales.data_ptr(), rotation.data_ptr(),
-                raw_opacity.data_ptr(), sh.data_ptr(), self.n, self.degree, moment1.data_ptr(), moment2.data_ptr(),
+                raw_opacity.data_ptr(), sh.data_ptr(), n, self.degree, moment1.data_ptr(), moment2.data_ptr(),
                 ptr(next_quats_fed), ptr(grad_2d_accum), ptr(xy_grad_counts), self.index.data_ptr(), ibytes,
                 torch.cuda.current_stream().cuda_stream), "brush_reduce_view_records_adam")
         self._keep = (view_rows, campos)

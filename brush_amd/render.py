@@ -25,6 +25,16 @@ from .camera import Camera
 # the reference's -12345 poison under cfg(test) (crates/brush-kernel/src/lib.rs:134-147).
 DEBUG_POISON = False
 
+# Deterministic gradients (BrushAux.flags & AUX_DETERMINISTIC), chosen per call: an explicit `deterministic=` argument
+# wins, then this module-level override, then the environment default brush_deterministic() (BRUSH_DETERMINISTIC=1).
+DETERMINISTIC: Optional[bool] = None
+
+
+def deterministic_default() -> bool:
+    if DETERMINISTIC is not None:
+        return bool(DETERMINISTIC)
+    return bool(_lib.lib().brush_deterministic())
+
 
 def sh_coeffs_for_degree(degree: int) -> int:
     """render.rs:40-42"""
@@ -62,8 +72,13 @@ class RenderAux:
     compact_from_global_gid: torch.Tensor  # [N] i32 (-1 = not visible)
     overflow: torch.Tensor                 # [1] i32, 1 if intersections were truncated
     max_intersects: int = 0
-    # deterministic mode (BRUSH_DETERMINISTIC=1) only: pre-sort position of every sorted intersection
+    # deterministic mode only: pre-sort position of every sorted intersection
     isect_unsorted_pos: Optional[torch.Tensor] = None
+    flags: int = 0                         # BrushAux.flags this render ran with (forward and backward agree)
+
+    @property
+    def deterministic(self) -> bool:
+        return bool(self.flags & _lib.AUX_DETERMINISTIC)
 
     def read_num_visible(self) -> int:
         """lib.rs:42-47 (a host readback; not on the hot path)."""
@@ -85,6 +100,7 @@ class RenderAux:
             setattr(s, name, getattr(self, name).data_ptr())
         s.max_intersects = int(self.max_intersects)
         s.isect_unsorted_pos = None if self.isect_unsorted_pos is None else self.isect_unsorted_pos.data_ptr()
+        s.flags = int(self.flags)
         return s
 
 
@@ -124,8 +140,10 @@ def _check_inputs(means, xy_dummy, log_scales, quats, sh_coeffs, raw_opacity):
 
 
 def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, raw_opacity, render_u32: bool,
-                  max_intersects: Optional[int], row_pitch: Optional[int] = None):
+                  max_intersects: Optional[int], row_pitch: Optional[int] = None,
+                  deterministic: Optional[bool] = None):
     l = _lib.lib()
+    det = deterministic_default() if deterministic is None else bool(deterministic)
     n = means.shape[0]
     w, h = int(img_size[0]), int(img_size[1])
     dev = means.device
@@ -149,7 +167,8 @@ def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, ra
         compact_from_global_gid=_empty((nn,), i32, dev),
         overflow=_empty((1,), i32, dev),
         max_intersects=cap,
-        isect_unsorted_pos=_empty((cap,), i32, dev) if l.brush_deterministic() else None,
+        isect_unsorted_pos=_empty((cap,), i32, dev) if det else None,
+        flags=_lib.AUX_DETERMINISTIC if det else 0,
     )
     if row_pitch is not None:
         if not render_u32 or row_pitch < w:
@@ -213,8 +232,8 @@ def _backward_impl(u, aux: RenderAux, means, log_scales, quats, raw_opacity, nco
         "v_opac": seg("v_opac", (n,)), "v_sh": seg("v_sh", (n, ncoef, 3)), "v_xy": seg("v_xy", (n, 2)),
     }
     nbytes = C.c_size_t()
-    _lib.check(l.brush_bwd_workspace_size_ex(n, w, h, int(u.sh_degree), int(aux.max_intersects), C.byref(nbytes)),
-               "brush_bwd_workspace_size_ex")
+    _lib.check(l.brush_bwd_workspace_size_flags(n, w, h, int(u.sh_degree), int(aux.max_intersects), int(aux.flags),
+                                                C.byref(nbytes)), "brush_bwd_workspace_size_flags")
     ws = _empty((max(nbytes.value, 1),), torch.uint8, dev)
     v_out = v_out.contiguous()
     s = aux._as_struct()
@@ -235,7 +254,7 @@ class _RenderSplatsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, xy_dummy, log_scales, quats, sh_coeffs, raw_opacity, holder):
         out, aux, u = _forward_impl(holder["cam"], holder["img_size"], means, log_scales, quats, sh_coeffs,
-                                    raw_opacity, False, holder["max_intersects"])
+                                    raw_opacity, False, holder["max_intersects"], deterministic=holder["deterministic"])
         holder["aux"] = aux
         ctx.u, ctx.aux, ctx.ncoef = u, aux, sh_coeffs.shape[1]
         ctx.save_for_backward(means, log_scales, quats, raw_opacity, out)
@@ -253,13 +272,15 @@ class _RenderSplatsFn(torch.autograd.Function):
 def render_splats(cam: Camera, img_size, means: torch.Tensor, xy_grad_dummy: Optional[torch.Tensor],
                   log_scales: torch.Tensor, quats: torch.Tensor, sh_coeffs: torch.Tensor,
                   raw_opacity: torch.Tensor, render_u32_buffer: bool = False,
-                  max_intersects: Optional[int] = None) -> Tuple[torch.Tensor, RenderAux]:
+                  max_intersects: Optional[int] = None,
+                  deterministic: Optional[bool] = None) -> Tuple[torch.Tensor, RenderAux]:
     """Backend::render_splats (lib.rs:75-85).
 
     Returns (img, aux): img is float32 [h,w,4] (rgb, 1-T; no background blend) or, with
     `render_u32_buffer`, int32 [h,w,1] packed RGBA8.  `xy_grad_dummy` only carries the
     screen-space xy gradient (global order, pixel units).  `max_intersects` defaults to the
-    reference's min(N*tiles, 128*65535); aux.overflow reports truncation.
+    reference's min(N*tiles, 128*65535); aux.overflow reports truncation.  `deterministic` (build extension)
+    selects bitwise reproducible gradients for this call (default: render.DETERMINISTIC, then BRUSH_DETERMINISTIC).
     """
     _check_inputs(means, xy_grad_dummy, log_scales, quats, sh_coeffs, raw_opacity)
     tracked = torch.is_grad_enabled() and not render_u32_buffer and any(
@@ -268,11 +289,11 @@ def render_splats(cam: Camera, img_size, means: torch.Tensor, xy_grad_dummy: Opt
         # UnTracked branch (render.rs:453-460): plain forward, no state kept.
         with torch.no_grad():
             out, aux, _ = _forward_impl(cam, img_size, means, log_scales, quats, sh_coeffs, raw_opacity,
-                                        render_u32_buffer, max_intersects)
+                                        render_u32_buffer, max_intersects, deterministic=deterministic)
         return out, aux
     if xy_grad_dummy is None:
         xy_grad_dummy = torch.zeros((means.shape[0], 2), dtype=torch.float32, device=means.device)
-    holder = {"cam": cam, "img_size": img_size, "max_intersects": max_intersects}
+    holder = {"cam": cam, "img_size": img_size, "max_intersects": max_intersects, "deterministic": deterministic}
     out = _RenderSplatsFn.apply(means, xy_grad_dummy, log_scales, quats, sh_coeffs, raw_opacity, holder)
     return out, holder["aux"]
 

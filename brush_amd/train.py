@@ -252,8 +252,9 @@ class SplatTrainer:
             elif grad_sync is None and self.fused_backward:
                 # single view: gradients go straight through the optimizer inside the backward kernel
                 nbytes = C.c_size_t()
-                _lib.check(l.brush_bwd_workspace_size_ex(n, w, h, int(u.sh_degree), int(aux.max_intersects),
-                                                         C.byref(nbytes)), "brush_bwd_workspace_size_ex")
+                _lib.check(l.brush_bwd_workspace_size_flags(n, w, h, int(u.sh_degree), int(aux.max_intersects),
+                                                            int(aux.flags), C.byref(nbytes)),
+                           "brush_bwd_workspace_size_flags")
                 ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=means.device)
                 v_xy = torch.empty((max(n, 1), 2), dtype=torch.float32, device=means.device)
                 s_aux = aux._as_struct()

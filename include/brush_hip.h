@@ -20,7 +20,8 @@
  *     allocates, frees or synchronises on these paths; all work is enqueued on `stream`
  *     (a hipStream_t) and the call returns immediately.  Data-dependent sizes
  *     (num_visible, num_intersections) stay on the device.
- *   - Functions are re-entrant: no global mutable state, per-call workspace.
+ *   - Functions are re-entrant: no global mutable state, per-call workspace; every mode switch is an argument
+ *     (BrushAux::flags), nothing on these paths reads the environment.
  *   - Return value: BRUSH_OK or a negative BrushStatus; nothing aborts.
  *   - All floating point is f32, all indices/counts u32 (i32-typed tensors in Burn).
  */
@@ -84,12 +85,22 @@ typedef struct BrushAux {
                                           map_gaussian_to_intersects.wgsl:40) */
     uint32_t max_intersects;           /* capacity; reference: min(N*tiles, 128*65535)
                                           (render.rs:204-206) */
-    uint32_t *isect_unsorted_pos;      /* [max_intersects] or NULL.  Deterministic mode (BRUSH_DETERMINISTIC=1,
-                                          brush_deterministic()) only: position each sorted intersection had in
+    uint32_t *isect_unsorted_pos;      /* [max_intersects] or NULL.  Deterministic mode (flags &
+                                          BRUSH_AUX_DETERMINISTIC) only: position each sorted intersection had in
                                           emission order (grouped by splat), written by the forward and used by
                                           the backward to sum a splat's per-tile gradient rows in a fixed order.
                                           Must be non-NULL in that mode, ignored otherwise. */
+    uint32_t flags;                    /* BRUSH_AUX_* bits, chosen PER CALL; the forward and the backward of one
+                                          render must be given the same value */
 } BrushAux;
+
+/* BrushAux::flags */
+#define BRUSH_AUX_DETERMINISTIC 1u /* bitwise reproducible gradients: the compositing backward stores one gradient
+                                      row per intersection and sums a splat's rows in a fixed order instead of
+                                      using hardware float atomics (whose arrival order is unspecified; the
+                                      reference's CAS queue, rasterize_backwards.wgsl:276-301, has the same
+                                      nondeterminism).  Needs isect_unsorted_pos and the larger backward workspace
+                                      of brush_bwd_workspace_size_flags. */
 
 /* ---- introspection ------------------------------------------------------------------ */
 const char *brush_version(void);
@@ -143,16 +154,18 @@ int brush_render_forward_rgba8(const BrushUniforms *uniforms, const float *means
                                void *workspace, size_t workspace_bytes, brush_stream_t stream);
 
 /* ---- render backward ------------------------------------------------------------------ */
-/* 1 when the process runs with BRUSH_DETERMINISTIC=1: gradients are then bitwise reproducible run to run (one
- * gradient row per intersection, summed per splat in a fixed order, instead of hardware float atomics whose
- * arrival order is unspecified; the reference's CAS queue, rasterize_backwards.wgsl:276-301, has the same
- * nondeterminism).  The mode needs BrushAux::isect_unsorted_pos and the larger workspace of
- * brush_bwd_workspace_size_ex. */
+/* A host-side DEFAULT for BrushAux::flags, nothing more: 1 when the environment holds BRUSH_DETERMINISTIC=1 (read
+ * on every call, never cached, never consulted by the render entry points themselves).  A host that wants the
+ * mode per call (a viewer thread beside a trainer task) sets or clears BRUSH_AUX_DETERMINISTIC itself. */
 int brush_deterministic(void);
+/* Backward workspace for a call with these BrushAux::flags and this intersection capacity (the deterministic mode
+ * keeps 64 bytes per intersection). */
+int brush_bwd_workspace_size_flags(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree, uint32_t max_intersects,
+                                   uint32_t flags, size_t *bytes);
+/* Shorthands: flags = 0 (the default mode); brush_bwd_workspace_size also assumes
+ * brush_default_max_intersects(n, w, h). */
 int brush_bwd_workspace_size(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree,
                              size_t *bytes);
-/* As above with the intersection capacity explicit (the deterministic mode keeps 64 bytes per intersection);
- * brush_bwd_workspace_size assumes brush_default_max_intersects(n, w, h). */
 int brush_bwd_workspace_size_ex(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_degree, uint32_t max_intersects,
                                 size_t *bytes);
 /* Gradients in the parent order of render.rs:420-427,598-624:

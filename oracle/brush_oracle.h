@@ -102,7 +102,18 @@ int oracle_render_backward_f64(const OracleUniforms *u, const OracleAux *aux, co
                                double *flip_means, double *flip_xy, double *flip_scales, double *flip_quats,
                                double *flip_sh, double *flip_opac,
                                /* and the magnitude of the terms the projection VJP itself sums */
-                               double *vjp_means, double *vjp_scales, double *vjp_quats);
+                               double *vjp_means, double *vjp_scales, double *vjp_quats,
+                               /* optional [h,w]: relative uncertainty of each pixel's forward state, added
+                                * (times the magnitude of the pixel's terms) to flip_* */
+                               const double *pix_weight,
+                               /* optional [h,w]: that other forward state's final_index (entries only one of the two
+                                * walks reach count towards flip_* in full) */
+                               const uint32_t *final_index_alt,
+                               /* mag_* with every term weighted by the number of divisions its T went through */
+                               double *dep_means, double *dep_xy, double *dep_scales, double *dep_quats,
+                               double *dep_sh, double *dep_opac,
+                               /* rounding magnitude of the SH basis / of the saturating sigmoid */
+                               double *vjp_sh, double *vjp_opac);
 
 /* Deterministic elementary functions (oracle/detmath.h), exported for tests. */
 float oracle_det_expf(float x);

@@ -129,49 +129,96 @@ static void dsh_basis(uint32_t degree, const double *d, double *Y) {
     Y[23] = fTmp2B * fC2; Y[17] = fTmp2B * fS2; Y[24] = fTmp3A * fC3; Y[16] = fTmp3A * fS3;
 }
 
+/* Magnitude companion of dsh_basis: every monomial with |x|, |y|, |z| and every subtraction turned into an addition,
+ * i.e. the sum of the magnitudes of the terms an f32 evaluation of Y_k adds up.  Where a basis polynomial passes
+ * through zero (Y6 = 0.946 z^2 - 0.315 at z^2 = 1/3, ...) its f32 rounding error is eps * this, not eps * |Y_k|. */
+static void dsh_basis_mag(uint32_t degree, const double *d, double *Y) {
+    double x = fabs(d[0]), y = fabs(d[1]), z = fabs(d[2]);
+    Y[0] = 0.2820947917738781;
+    if (degree == 0) return;
+    double fTmp0A = 0.48860251190292;
+    Y[2] = fTmp0A * z; Y[3] = fTmp0A * x; Y[1] = fTmp0A * y;
+    if (degree == 1) return;
+    double z2 = z * z;
+    double fTmp0B = 1.092548430592079 * z;
+    double fTmp1A = 0.5462742152960395;
+    double fC1 = x * x + y * y, fS1 = 2.0 * x * y;
+    Y[6] = 0.9461746957575601 * z2 + 0.3153915652525201;
+    Y[7] = fTmp0B * x; Y[5] = fTmp0B * y; Y[8] = fTmp1A * fC1; Y[4] = fTmp1A * fS1;
+    if (degree == 2) return;
+    double fTmp0C = 2.285228997322329 * z2 + 0.4570457994644658;
+    double fTmp1B = 1.445305721320277 * z;
+    double fTmp2A = 0.5900435899266435;
+    double fC2 = x * fC1 + y * fS1, fS2 = x * fS1 + y * fC1;
+    Y[12] = z * (1.865881662950577 * z2 + 1.119528997770346);
+    Y[13] = fTmp0C * x; Y[11] = fTmp0C * y; Y[14] = fTmp1B * fC1; Y[10] = fTmp1B * fS1;
+    Y[15] = fTmp2A * fC2; Y[9] = fTmp2A * fS2;
+    if (degree == 3) return;
+    double fTmp0D = z * (4.683325804901025 * z2 + 2.007139630671868);
+    double fTmp1C = 3.31161143515146 * z2 + 0.47308734787878;
+    double fTmp2B = 1.770130769779931 * z;
+    double fTmp3A = 0.6258357354491763;
+    double fC3 = x * fC2 + y * fS2, fS3 = x * fS2 + y * fC2;
+    Y[20] = 1.984313483298443 * z * Y[12] + 1.006230589874905 * Y[6];
+    Y[21] = fTmp0D * x; Y[19] = fTmp0D * y; Y[22] = fTmp1C * fC1; Y[18] = fTmp1C * fS1;
+    Y[23] = fTmp2B * fC2; Y[17] = fTmp2B * fS2; Y[24] = fTmp3A * fC3; Y[16] = fTmp3A * fS3;
+}
+
 /* rasterize_backwards.wgsl:140-304, one tile; values f64, decisions as the f32 restatement. */
 static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id, const uint32_t *gid_from_isect,
                                       const uint32_t *tile_bins, const float *projected,
                                       const uint32_t *final_index, const float *out_img, const float *v_out,
                                       double *rows /* [I][9] */, double *rows_abs /* [I][9] sums of |terms| */,
-                                      double *rows_flip /* [I][9] what flipped threshold decisions can move */) {
+                                      double *rows_flip /* [I][9] what flipped threshold decisions can move */,
+                                      double *rows_dep /* [I][9] sums of |terms| x (divisions T went through) */,
+                                      const double *pix_weight /* optional [h,w], see oracle_render_backward_f64 */,
+                                      const uint32_t *final_index_alt /* optional [h,w], likewise */) {
     uint32_t w = u->img_size[0], h = u->img_size[1], tbx = u->tile_bounds[0];
     uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
     uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
     if (r1 <= r0) return;
     double T[TILE_SIZE], T_final[TILE_SIZE], buf[TILE_SIZE][3], vo[TILE_SIZE][4];
     float pcx[TILE_SIZE], pcy[TILE_SIZE];
-    uint32_t fin[TILE_SIZE];
+    uint32_t fin[TILE_SIZE], fin_lo[TILE_SIZE], fin_hi[TILE_SIZE];
     uint8_t inside[TILE_SIZE];
     /* relative change of T at pixel l if the threshold decisions met so far on it went the other way */
-    double flip_w[TILE_SIZE];
+    double flip_w[TILE_SIZE], pix_w[TILE_SIZE];
+    double ntaken[TILE_SIZE]; /* roundings (in eps) the recovered T of pixel l has gone through so far */
     for (uint32_t l = 0; l < TILE_SIZE; l++) {
         uint32_t px = tile_x * TILE_WIDTH + l % TILE_WIDTH, py = tile_y * TILE_WIDTH + l / TILE_WIDTH;
         inside[l] = px < w && py < h;
         pcx[l] = (float)px + 0.5f; pcy[l] = (float)py + 0.5f;
         flip_w[l] = 0.0;
+        pix_w[l] = 0.0;
+        ntaken[l] = 0.0;
         buf[l][0] = buf[l][1] = buf[l][2] = 0.0;
-        fin[l] = 0; T[l] = T_final[l] = 1.0;
+        fin[l] = fin_lo[l] = fin_hi[l] = 0; T[l] = T_final[l] = 1.0;
         vo[l][0] = vo[l][1] = vo[l][2] = vo[l][3] = 0.0;
         if (inside[l]) {
             size_t pix = (size_t)px + (size_t)py * w;
             T_final[l] = 1.0 - (double)out_img[pix * 4 + 3];
             T[l] = T_final[l];
-            fin[l] = final_index[pix];
+            fin[l] = fin_lo[l] = fin_hi[l] = final_index[pix];
+            if (final_index_alt) {
+                uint32_t alt = final_index_alt[pix];
+                fin_lo[l] = alt < fin[l] ? alt : fin[l];
+                fin_hi[l] = alt > fin[l] ? alt : fin[l];
+            }
+            if (pix_weight) pix_w[l] = pix_weight[pix];
             for (int k = 0; k < 4; k++) vo[l][k] = (double)v_out[pix * 4 + k];
         }
     }
     for (uint32_t i = r1; i-- > r0;) {
         const float *p = projected + (size_t)gid_from_isect[i] * 9;
         double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        double sf[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double sf[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (uint32_t l = 0; l < TILE_SIZE; l++) {
-            if (!(inside[l] && i <= fin[l])) continue;
+            if (!(inside[l] && i <= fin_hi[l])) continue;
             /* decision: exactly brush_oracle.c (f32) */
             float fdx = p[0] - pcx[l], fdy = p[1] - pcy[l];
             float fsigma = 0.5f * (p[2] * fdx * fdx + p[4] * fdy * fdy) + p[3] * fdx * fdy;
             float falpha = fminf(0.99f, p[8] * expf(-fsigma));
-            int take = fsigma >= 0.0f && falpha >= 1.0f / 255.0f;
+            int take = fsigma >= 0.0f && falpha >= 1.0f / 255.0f && i <= fin[l];
             /* A decision another f32 evaluation (different exp, contraction, association) may take the other
              * way.  sigma is a sum of terms of total magnitude fterms, so two f32 evaluations of it differ by up to
              * a few eps * fterms (far more than eps * sigma when the conic is strongly correlated and the terms
@@ -181,6 +228,9 @@ static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
             float dsig = 4.8e-7f * fterms; /* 8 eps32 * fterms */
             int risky = (fabsf(falpha * 255.0f - 1.0f) < 1e-6f + dsig && fsigma >= -dsig) ||
                         (fabsf(fsigma) <= dsig && p[8] >= 1.0f / 255.0f);
+            /* an entry only ONE of the two forward states walks (the saturation stop of rasterize.wgsl:88-91 fell on a
+             * different entry): present in one backward, absent from the other */
+            if (i > fin_lo[l] && fsigma >= 0.0f && falpha >= 1.0f / 255.0f) risky = 1;
             if (!take && !risky) continue;
             /* values: f64 */
             double dx = (double)p[0] - (double)pcx[l], dy = (double)p[1] - (double)pcy[l];
@@ -214,10 +264,16 @@ static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
                 s[5] += fac * vo[l][0]; s[6] += fac * vo[l][1]; s[7] += fac * vo[l][2];
                 s[8] += vis * v_alpha;
                 for (int k = 0; k < 9; k++) sa[k] += ma[k];
+                /* T (and with it every term of this entry) is T_final divided by the f32 (1 - alpha) of every entry walked
+                 * so far (rasterize_backwards.wgsl:244-246).  Each division costs a rounding, and (1 - alpha) itself is
+                 * the difference of 1 and a rounded alpha: its relative error is eps alpha / (1 - alpha), up to 99 eps
+                 * at the 0.99 clamp.  ntaken counts those roundings in units of eps. */
+                ntaken[l] += 1.0 + alpha * ra;
+                for (int k = 0; k < 9; k++) sd[k] += ma[k] * ntaken[l];
             }
             /* flips: this record's own terms if ITS decision is risky (taken or not: the other evaluation does the
              * opposite); every term of a pixel whose T already carries possible flips of relative size flip_w */
-            double wgt = (risky ? 1.0 : 0.0) + (take ? flip_w[l] : 0.0);
+            double wgt = (risky ? 1.0 : 0.0) + (take ? flip_w[l] + pix_w[l] : 0.0);
             if (wgt > 0.0)
                 for (int k = 0; k < 9; k++) sf[k] += wgt * ma[k];
             if (risky) flip_w[l] += alpha * ra * 1.05; /* T of the later-walked entries changes by 1/(1 - alpha) */
@@ -225,6 +281,7 @@ static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
         for (int k = 0; k < 9; k++) rows[(size_t)i * 9 + k] = s[k];
         for (int k = 0; k < 9; k++) rows_abs[(size_t)i * 9 + k] = sa[k];
         for (int k = 0; k < 9; k++) rows_flip[(size_t)i * 9 + k] = sf[k];
+        for (int k = 0; k < 9; k++) rows_dep[(size_t)i * 9 + k] = sd[k];
     }
 }
 
@@ -383,7 +440,15 @@ static void d_project_backward_mag(const OracleUniforms *u, const float *fmean, 
  * flip_* : how far the element can move when the threshold decisions that sit within f32 rounding of
  * flipping (alpha ~ 1/255, sigma ~ 0) go the other way in another f32 evaluation: the flipped entry's own
  * terms plus alpha/(1-alpha) of every term the pixel contributes afterwards (T is recovered by division).
- * vjp_*  : magnitude of the terms the projection VJP itself adds up for the element (d_project_backward_mag). */
+ * vjp_*  : magnitude of the terms the projection VJP itself adds up for the element (d_project_backward_mag); for
+ *   v_sh the terms of the SH basis polynomial, for v_opac the saturating sigmoid's (1 - s).
+ * dep_*  : like mag_*, every term weighted by the number of f32 divisions its recovered T has gone through.
+ * pix_weight (optional, [h,w]): a relative uncertainty of the pixel's forward state (every term of a pixel is
+ *   proportional to T_final = 1 - out.a, rasterize_backwards.wgsl:163,173); weight x |terms| of the pixel is added to
+ *   flip_*.  Used when the gradients under test come from a DIFFERENT forward state than the one passed here.
+ * final_index_alt (optional, [h,w]): that other forward state's final_index.  Where the two differ (the saturation
+ *   stop `T (1 - alpha) <= 1e-4`, rasterize.wgsl:88-91, fell on a different entry) the entries between them exist in
+ *   one backward only: their own terms go to flip_* in full, and the pixel's other terms get alpha / (1 - alpha). */
 int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux, const float *means,
                                const float *log_scales, const float *quats, const float *raw_opac, uint32_t n,
                                const float *out_img, const float *v_out, double *v_means, double *v_xy,
@@ -391,7 +456,9 @@ int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux,
                                double *mag_xy, double *mag_scales, double *mag_quats, double *mag_sh,
                                double *mag_opac, double *flip_means, double *flip_xy, double *flip_scales,
                                double *flip_quats, double *flip_sh, double *flip_opac, double *vjp_means,
-                               double *vjp_scales, double *vjp_quats) {
+                               double *vjp_scales, double *vjp_quats, const double *pix_weight,
+                               const uint32_t *final_index_alt, double *dep_means, double *dep_xy, double *dep_scales,
+                               double *dep_quats, double *dep_sh, double *dep_opac, double *vjp_sh, double *vjp_opac) {
     OracleUniforms uu = *u_in;
     uu.total_splats = n;
     const OracleUniforms *u = &uu;
@@ -404,10 +471,13 @@ int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux,
     double *acc_abs = (double *)calloc((size_t)(V ? V : 1) * 9, sizeof(double));
     double *rows_flip = (double *)calloc((size_t)(I ? I : 1) * 9, sizeof(double));
     double *acc_flip = (double *)calloc((size_t)(V ? V : 1) * 9, sizeof(double));
+    double *rows_dep = (double *)calloc((size_t)(I ? I : 1) * 9, sizeof(double));
+    double *acc_dep = (double *)calloc((size_t)(V ? V : 1) * 9, sizeof(double));
 #pragma omp parallel for schedule(dynamic, 4)
     for (int64_t t = 0; t < (int64_t)num_tiles; t++)
         d_rasterize_backward_tile(u, (uint32_t)t, aux->compact_gid_from_isect, aux->tile_bins, aux->projected_splats,
-                                  aux->final_index, out_img, v_out, rows, rows_abs, rows_flip);
+                                  aux->final_index, out_img, v_out, rows, rows_abs, rows_flip, rows_dep, pix_weight,
+                                  final_index_alt);
     for (size_t i = 0; i < I; i++) { /* fixed order: ascending intersection id */
         double *a = acc + (size_t)aux->compact_gid_from_isect[i] * 9;
         double *m = acc_abs + (size_t)aux->compact_gid_from_isect[i] * 9;
@@ -415,6 +485,8 @@ int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux,
         for (int k = 0; k < 9; k++) m[k] += rows_abs[i * 9 + k];
         double *f = acc_flip + (size_t)aux->compact_gid_from_isect[i] * 9;
         for (int k = 0; k < 9; k++) f[k] += rows_flip[i * 9 + k];
+        double *dp = acc_dep + (size_t)aux->compact_gid_from_isect[i] * 9;
+        for (int k = 0; k < 9; k++) dp[k] += rows_dep[i * 9 + k];
     }
     if (mag_means) {
         memset(mag_means, 0, sizeof(double) * 3 * n);
@@ -432,6 +504,14 @@ int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux,
         memset(vjp_means, 0, sizeof(double) * 3 * n);
         memset(vjp_scales, 0, sizeof(double) * 3 * n);
         memset(vjp_quats, 0, sizeof(double) * 4 * n);
+        memset(dep_means, 0, sizeof(double) * 3 * n);
+        memset(dep_xy, 0, sizeof(double) * 2 * n);
+        memset(dep_scales, 0, sizeof(double) * 3 * n);
+        memset(dep_quats, 0, sizeof(double) * 4 * n);
+        memset(dep_sh, 0, sizeof(double) * 3 * (size_t)ncoef * n);
+        memset(dep_opac, 0, sizeof(double) * n);
+        memset(vjp_sh, 0, sizeof(double) * 3 * (size_t)ncoef * n);
+        memset(vjp_opac, 0, sizeof(double) * n);
     }
     memset(v_means, 0, sizeof(double) * 3 * n);
     memset(v_xy, 0, sizeof(double) * 2 * n);
@@ -461,19 +541,32 @@ int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux,
         d_project_backward_one(u, mean, log_scales + (size_t)g * 3, quats + (size_t)g * 4, a, a + 2,
                                v_means + (size_t)g * 3, v_scales + (size_t)g * 3, v_quats + (size_t)g * 4);
         if (mag_means) {
-            const double *m = acc_abs + (size_t)c * 9, *fl = acc_flip + (size_t)c * 9;
+            const double *m = acc_abs + (size_t)c * 9, *fl = acc_flip + (size_t)c * 9, *dp = acc_dep + (size_t)c * 9;
             double *ms = mag_sh + (size_t)g * ncoef * 3, *fs = flip_sh + (size_t)g * ncoef * 3;
+            double *ds = dep_sh + (size_t)g * ncoef * 3, *vs2 = vjp_sh + (size_t)g * ncoef * 3;
+            double Ym[25];
+            dsh_basis_mag(u->sh_degree, dir, Ym);
             for (uint32_t k = 0; k < ncoef; k++)
                 for (int ch = 0; ch < 3; ch++) {
                     ms[k * 3 + ch] = fabs(Y[k]) * m[5 + ch];
                     fs[k * 3 + ch] = fabs(Y[k]) * fl[5 + ch];
+                    ds[k * 3 + ch] = fabs(Y[k]) * dp[5 + ch];
+                    /* rounding noise of the SH basis itself (gather_grads.wgsl:17-112 evaluated in f32): the terms of
+                     * Y_k by magnitude, once more per degree for the normalised direction they are built from */
+                    vs2[k * 3 + ch] = (1.0 + (double)u->sh_degree) * Ym[k] * fabs(a[5 + ch]);
                 }
             mag_opac[g] = m[8] * (s * (1.0 - s));
             flip_opac[g] = fl[8] * (s * (1.0 - s));
+            dep_opac[g] = dp[8] * (s * (1.0 - s));
+            /* v_opac = v * s (1 - s) (gather_grads.wgsl:224-227): the f32 (1 - s) carries an absolute error eps s, i.e. a
+             * relative one of eps s / (1 - s) that no summation magnitude sees when the sigmoid saturates */
+            vjp_opac[g] = fabs(a[8]) * s;
             mag_xy[(size_t)g * 2] = m[0];
             mag_xy[(size_t)g * 2 + 1] = m[1];
             flip_xy[(size_t)g * 2] = fl[0];
             flip_xy[(size_t)g * 2 + 1] = fl[1];
+            dep_xy[(size_t)g * 2] = dp[0];
+            dep_xy[(size_t)g * 2 + 1] = dp[1];
             d_project_backward_mag(u, mean, log_scales + (size_t)g * 3, quats + (size_t)g * 4, a, a + 2,
                                    vjp_means + (size_t)g * 3, vjp_scales + (size_t)g * 3, vjp_quats + (size_t)g * 4);
             /* the projection VJP is linear in (v_xy, v_conic): its columns, one unit input at a time */
@@ -487,10 +580,13 @@ int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux,
                 for (int j = 0; j < 3; j++) flip_means[(size_t)g * 3 + j] += fabs(om[j]) * fl[k];
                 for (int j = 0; j < 3; j++) flip_scales[(size_t)g * 3 + j] += fabs(os[j]) * fl[k];
                 for (int j = 0; j < 4; j++) flip_quats[(size_t)g * 4 + j] += fabs(oq[j]) * fl[k];
+                for (int j = 0; j < 3; j++) dep_means[(size_t)g * 3 + j] += fabs(om[j]) * dp[k];
+                for (int j = 0; j < 3; j++) dep_scales[(size_t)g * 3 + j] += fabs(os[j]) * dp[k];
+                for (int j = 0; j < 4; j++) dep_quats[(size_t)g * 4 + j] += fabs(oq[j]) * dp[k];
             }
         }
     }
-    free(rows); free(acc); free(rows_abs); free(acc_abs); free(rows_flip); free(acc_flip);
+    free(rows); free(acc); free(rows_abs); free(acc_abs); free(rows_flip); free(acc_flip); free(rows_dep); free(acc_dep);
     return 0;
 }
 

@@ -282,11 +282,16 @@ def rasterize_forward_f64(u: dict, aux: dict):
     return out, cond
 
 
-def render_backward_f64(u: dict, aux: dict, means, log_scales, quats, raw_opac, out_img, v_out):
+def render_backward_f64(u: dict, aux: dict, means, log_scales, quats, raw_opac, out_img, v_out, pix_weight=None,
+                        final_index_alt=None):
     """The f64 arbiter (brush_oracle_f64.c): same inputs / forward state, every value in double, the walk's
     decisions as the f32 restatement takes them.  Returns float64 dense grads and, under "mag_<name>", the sum of
     the magnitudes of the terms each element is made of (|f32 result - exact| <= eps_per_term * mag) and, under
-    "flip_<name>", what the threshold decisions within f32 rounding of flipping can move."""
+    "flip_<name>", what the threshold decisions within f32 rounding of flipping can move.  pix_weight ([h,w],
+    optional): relative uncertainty of each pixel's forward state (T_final); weight x |terms of the pixel| is added
+    to the flip allowance (for gradients computed from a different forward state than the one passed here);
+    final_index_alt ([h,w] uint32, optional): that other state's final_index — entries only one of the two walks
+    reaches count towards the flip allowance in full."""
     means, log_scales, quats, raw_opac = _f32(means), _f32(log_scales), _f32(quats), _f32(raw_opac)
     out_img, v_out = _f32(out_img), _f32(v_out)
     n = means.shape[0]
@@ -299,7 +304,8 @@ def render_backward_f64(u: dict, aux: dict, means, log_scales, quats, raw_opac, 
     for k in list(g):
         g["mag_" + k[2:]] = np.zeros_like(g[k])
         g["flip_" + k[2:]] = np.zeros_like(g[k])
-    for k in ("means", "scales", "quats"):
+        g["dep_" + k[2:]] = np.zeros_like(g[k])
+    for k in ("means", "scales", "quats", "sh", "opac"):
         g["vjp_" + k] = np.zeros_like(g["v_" + k])
     s = _Aux()
     for k in ("projected_splats", "num_intersections", "num_visible", "final_index", "cum_tiles_hit",
@@ -314,5 +320,10 @@ def render_backward_f64(u: dict, aux: dict, means, log_scales, quats, raw_opac, 
                                      _p(g["mag_sh"]), _p(g["mag_opac"]),
                                      _p(g["flip_means"]), _p(g["flip_xy"]), _p(g["flip_scales"]), _p(g["flip_quats"]),
                                      _p(g["flip_sh"]), _p(g["flip_opac"]),
-                                     _p(g["vjp_means"]), _p(g["vjp_scales"]), _p(g["vjp_quats"]))
+                                     _p(g["vjp_means"]), _p(g["vjp_scales"]), _p(g["vjp_quats"]),
+                                     _p(None if pix_weight is None else np.ascontiguousarray(pix_weight, np.float64)),
+                                     _p(None if final_index_alt is None else
+                                        np.ascontiguousarray(final_index_alt, np.uint32)),
+                                     _p(g["dep_means"]), _p(g["dep_xy"]), _p(g["dep_scales"]), _p(g["dep_quats"]),
+                                     _p(g["dep_sh"]), _p(g["dep_opac"]), _p(g["vjp_sh"]), _p(g["vjp_opac"]))
     return g

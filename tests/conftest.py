@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU runs leave the measured parity margins in gpurun_out/parity_margins.json (tests/margins.py)."""
+    try:
+        from tests import margins
+
+        path = margins.flush()
+        if path:
+            print(f"\nparity margins written to {path}")
+    except Exception as e:  # never turn a finished run red from here
+        print(f"\nparity margins not written: {e!r}")

@@ -12,6 +12,7 @@ import pytest
 
 from oracle import oracle as O
 from tests import helpers as H
+from tests import margins as M
 
 pytestmark = pytest.mark.gpu
 
@@ -148,10 +149,24 @@ def _run_pair(dev, cloud, w, h, sh_degree, max_intersects=None, v_out=None, came
                                 cloud["raw_opac"], g_out, v_out, f32_sums=True)
     o_g_f64 = O.render_backward_f64(u, shared_aux, cloud["means"], cloud["log_scales"], cloud["quats"],
                                     cloud["raw_opac"], g_out, v_out)
+    # End to end through the arbiter as well: the f64 backward on the ORACLE's forward state, told per pixel how far the
+    # GPU's forward state is from it.  Every term of a pixel is proportional to T_final = 1 - out.a
+    # (rasterize_backwards.wgsl:163,173), so a relative difference dT / T of a pixel moves each of its terms by that
+    # fraction: weight = 3 |T_gpu - T_oracle| / min(T) where both forwards stopped at the same entry.  Where they did not
+    # (the saturation stop of rasterize.wgsl:88-91 sits within rounding of its threshold) T_final differs by the
+    # skipped entries' (1 - alpha) factors, which cancel again in every T the backward recovers; what does differ is
+    # the set of entries walked, so the arbiter is given both final_index maps and prices the entries in between.
+    T_g = 1.0 - g_out[..., 3].astype(np.float64)
+    T_o = 1.0 - o_out[..., 3].astype(np.float64)
+    fin_g = _np_u32(aux.final_index)
+    weight = np.where(fin_g == o_aux["final_index"], 3.0 * np.abs(T_g - T_o) / np.maximum(np.minimum(T_g, T_o), 1e-5), 0.0)
+    o_g_f64_e2e = O.render_backward_f64(u, o_aux, cloud["means"], cloud["log_scales"], cloud["quats"],
+                                        cloud["raw_opac"], o_out, v_out, pix_weight=weight, final_index_alt=fin_g)
     gpu = dict(out=g_out, aux=aux, u=u,
                v_means=params["means"].grad, v_scales=params["log_scales"].grad, v_quats=params["quats"].grad,
                v_sh=params["sh"].grad, v_opac=params["raw_opac"].grad, v_xy=xy.grad)
-    return gpu, dict(out=o_out, aux=o_aux, grads=o_g, grads_shared=o_g_shared, grads_f32=o_g_f32, grads_f64=o_g_f64)
+    return gpu, dict(out=o_out, aux=o_aux, grads=o_g, grads_shared=o_g_shared, grads_f32=o_g_f32, grads_f64=o_g_f64,
+                     grads_f64_e2e=o_g_f64_e2e)
 
 
 def _arbiter_report(gpu, orc, tag=""):
@@ -176,7 +191,11 @@ def _arbiter_report(gpu, orc, tag=""):
     return rep
 
 
-def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0):
+def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0, named=False):
+    """named: one of the scenes BASELINE.json names (S1, S4 / c1, c2, c3): on top of the conditioning-aware allowance
+    the HARD ceilings hold there — max |gpu - f64| <= 1e-4 flat (the north-star's L-inf figure, no allowance), no
+    pixel whose allowance exceeds 2e-4 and at most 1e-3 of the pixels above 1.2e-4 (so the allowance cannot quietly
+    become the test), at most 2e-3 of the pixels inside a threshold guard band."""
     aux, oa = gpu["aux"], orc["aux"]
     V, I = int(oa["num_visible"][0]), int(oa["num_intersections"][0])
     assert aux.read_num_visible() == V
@@ -210,6 +229,8 @@ def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0):
     lens = (oa["tile_bins"][..., 1].astype(np.int64) - oa["tile_bins"][..., 0].astype(np.int64)).reshape(-1)
     depth = float(lens[lens > 0].mean()) if (lens > 0).any() else 0.0
     assert risk.mean() < 2e-3 + 2e-5 * depth or risk.sum() <= 16, (float(risk.mean()), depth)
+    if named:
+        assert risk.mean() < 2e-3, float(risk.mean())
     diff = np.abs(gpu["out"] - orc["out"]).max(axis=2)
     exact, cond = O.rasterize_forward_f64(gpu["u"], oa)
     gpu_err = np.abs(gpu["out"].astype(np.float64) - exact).max(axis=2)
@@ -217,10 +238,19 @@ def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0):
     over = (gpu_err > tol) & ~risk
     assert not over.any(), (f"{int(over.sum())} pixels: max |gpu - f64| {gpu_err[over].max()} (allowance {tol[over].min()}); "
                             f"max |gpu - f32 restatement| {diff[~risk].max()}")
-    print(f"pixels: max |gpu - f64| {gpu_err[~risk].max():.2e}, median allowance {np.median(tol):.2e}, "
+    print(f"pixels: max |gpu - f64| {gpu_err[~risk].max():.2e}, median allowance {np.median(tol):.2e}, max {tol.max():.2e}, "
           f"pixels whose allowance exceeds 2e-4: {int((tol > 2e-4).sum())} of {tol.size}")
+    pix_ratio = float((gpu_err / tol)[~risk].max()) if (~risk).any() else 0.0
+    M.record("pixels", "summary", dict(worst=pix_ratio, max_gpu_minus_f64=float(gpu_err[~risk].max()), allowance_max=float(tol.max()),
+                                       allowance_median=float(np.median(tol)), over_2e_4=int((tol > 2e-4).sum()),
+                                       flip_risk_frac=float(risk.mean()), max_gpu_minus_f32_restatement=float(diff[~risk].max()),
+                                       named=bool(named)))
+    M.check_growth("pixels", "summary", pix_ratio)
+    if named:
+        assert gpu_err[~risk].max() <= PIX_TOL, gpu_err[~risk].max()
+        assert not (tol > 2e-4).any(), f"named scene: pixel allowance reaches {tol.max():.3e}"
+        assert (tol > 1.2e-4).mean() <= 1e-3, float((tol > 1.2e-4).mean())
     assert diff.max() <= 2.0 / 255.0 + 2.0 * tol.max()
-    gpu["pixel_allowance_max"] = float(tol.max())  # the end-to-end gradient check scales with the forward's conditioning
     fi = _np_u32(aux.final_index)
     differ = (fi != oa["final_index"]) & ~risk
     if saturation_flip_frac == 0.0:
@@ -243,58 +273,113 @@ def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0):
 #   |gpu - f64| <= RTOL |f64|                      the reference's own rtol (render.rs:815-830)
 #                + C_TERM eps32 mag               mag = sum of the MAGNITUDES of the per-pixel terms the element is
 #                                                 made of (f64 arbiter, carried through |gather / projection VJP|):
-#                                                 a per-term relative accuracy of C_TERM eps32 = 4e-6, whatever the
+#                                                 a per-term relative accuracy of C_TERM eps32, whatever the
 #                                                 summation order (v_exp_f32 + f32 exponent argument: ~5 eps per
-#                                                 alpha, amplified by alpha / (1 - alpha) <= 99 where T is
-#                                                 recovered by division, rasterize_backwards.wgsl:244-246)
+#                                                 alpha)
+#                + C_DEPTH eps32 dep              dep = the same terms, each weighted by the roundings (in eps) its
+#                                                 recovered T has gone through: T is T_final divided by the f32
+#                                                 (1 - alpha) of every entry walked so far
+#                                                 (rasterize_backwards.wgsl:244-246), one rounding per division plus
+#                                                 alpha / (1 - alpha) <= 99 for the cancellation in 1 - alpha: on a
+#                                                 list hundreds of entries deep the rounding of T, not of the term,
+#                                                 is what limits an f32 evaluation
 #                + C_FLIP flip                    what the threshold decisions that sit within f32 rounding of
 #                                                 flipping (alpha ~ 1/255, sigma ~ 0) can move (arbiter)
-#                + C_VJP eps32 vjp                v_means / v_scales / v_quats only: the rounding noise of the
-#                                                 projection VJP itself; vjp = the sum of the magnitudes of the terms
+#                + C_VJP eps32 vjp                the rounding noise of the per-splat VJP itself (v_sh: the terms of the
+#                                                 SH basis polynomial, which passes through zero; v_opac: the (1 - s)
+#                                                 of a saturating sigmoid); v_means / v_scales / v_quats: the
+#                                                 projection VJP; vjp = the sum of the magnitudes of the terms
 #                                                 it adds up (terms of size scale^2 cancel in v_V = T^t v_cov T and in
 #                                                 the column dot products of v_scale), evaluated by the arbiter.  The
 #                                                 GPU runs the same expression trees (-ffp-contract=off) on inputs that
 #                                                 differ in the last bits, so its noise is a different sample of it.
 #                + C_REF rowmax|oracle_f32 - f64| the error the f32 restatement of the reference makes on this row
-RTOL, C_TERM, C_FLIP, C_VJP, C_REF = 1e-4, 64.0, 1.5, 16.0, 4.0
+# The constants are CALIBRATED, not guessed: every run evaluates the candidate sets below and records each one's worst
+# err/tol per test and tensor (profiles/parity_margins.json); the active set is the tightest whose worst ratio over the
+# elements WITHOUT a flip allowance stays <= 1/4 on every test of the suite in both modes (i.e. each constant is at most
+# 4x what was ever observed).  On top of the allowance, no test's worst ratio may grow past 2x its tracked value
+# (tests/margins.py): a kernel change that makes the gradients several times less accurate turns the suite red even
+# though it still fits the mechanism-based bound (BRUSH_INJECT_VVA_ULPS build, tests/test_gpu_gate.py).
+RTOL, C_FLIP = 1e-4, 1.5
+CANDIDATES = {                      # (C_TERM, C_DEPTH, C_VJP, C_REF)
+    "r2": (64.0, 0.0, 16.0, 4.0),   # round 2's set (no depth term, the f32 restatement's own error x 4)
+    "a": (8.0, 1.0, 8.0, 1.0),
+    "b": (8.0, 0.5, 8.0, 1.0),
+    "c": (4.0, 1.0, 4.0, 1.0),
+    "d": (4.0, 0.5, 4.0, 0.0),
+    "e": (8.0, 1.0, 8.0, 0.0),
+    "f": (4.0, 0.25, 4.0, 1.0),
+    "g": (8.0, 0.25, 8.0, 1.0),
+}
+ACTIVE = "a"
+C_TERM, C_DEPTH, C_VJP, C_REF = CANDIDATES[ACTIVE]
+GRAD_NAMES = ("v_means", "v_scales", "v_quats", "v_sh", "v_opac", "v_xy")
+
+
+def _grad_ratio(a, f64, f32_err_rowmax, name, consts):
+    """err / tol per element of one tensor for one constant set; returns (ratio, err, parts)."""
+    c_term, c_dep, c_vjp, c_ref = consts
+    t = f64[name]
+    mag, flip, dep = f64["mag_" + name[2:]], f64["flip_" + name[2:]], f64["dep_" + name[2:]]
+    vjp = f64.get("vjp_" + name[2:], 0.0)
+    parts = (RTOL * np.abs(t), EPS32 * (c_term * mag + c_dep * dep), C_FLIP * flip, c_vjp * EPS32 * vjp + 0.0 * mag,
+             c_ref * f32_err_rowmax)
+    tol = parts[0] + parts[1] + parts[2] + parts[3] + parts[4] + 1e-300
+    err = np.abs(a - t)
+    return err / tol, err, parts
+
+
+def _rowmax(x, shape):
+    n = shape[0]
+    return x.reshape(n, -1).max(axis=1).reshape((n,) + (1,) * (len(shape) - 1)) if n else x
 
 
 def _assert_grad_parity(gpu, orc, tag=""):
-    """GPU gradients against the f64 arbiter fed with the forward state the GPU backward consumed; plus a loose
-    end-to-end check against the oracle's own forward state (T_final = 1 - out.a amplification, see _run_pair)
-    and exact zeros off the visible set."""
+    """GPU gradients against the f64 arbiter, element by element, twice: fed with the forward state the GPU backward
+    consumed (`shared`), and end to end against the arbiter on the oracle's own forward state with the measured
+    per-pixel difference of the two forward states folded into the flip allowance (`e2e`, see _run_pair; T_final =
+    1 - out.a turns a 1-ulp difference of out.a into 1e-4 of T on nearly opaque pixels — inherent to the reference's
+    formulation, and now priced per element instead of by a fraction of the tensor's maximum).  Plus exact zeros off
+    the visible set.  Records every margin (tests/margins.py) and asserts none has grown past 2x its tracked value."""
     V = int(orc["aux"]["num_visible"][0])
-    f64 = orc["grads_f64"]
     worst = {}
-    for name in ("v_means", "v_scales", "v_quats", "v_sh", "v_opac", "v_xy"):
-        t = f64[name]
-        a = gpu[name].detach().cpu().numpy().astype(np.float64).reshape(t.shape)
-        n = t.shape[0]
-        mag, flip = f64["mag_" + name[2:]], f64["flip_" + name[2:]]
-        ref_err = np.abs(orc["grads_f32"][name].astype(np.float64).reshape(t.shape) - t)
-        row_ref = ref_err.reshape(n, -1).max(axis=1).reshape((n,) + (1,) * (t.ndim - 1)) if n else ref_err
-        vjp = f64.get("vjp_" + name[2:], 0.0)
-        tol = RTOL * np.abs(t) + C_TERM * EPS32 * mag + C_FLIP * flip + C_VJP * EPS32 * vjp + C_REF * row_ref + 1e-300
-        err = np.abs(a - t)
-        ratio = err / tol
-        i = int(np.argmax(ratio)) if ratio.size else 0
-        worst[name] = float(ratio.reshape(-1)[i]) if ratio.size else 0.0
-        if ratio.size:
-            parts = [float(np.broadcast_to(x, t.shape).reshape(-1)[i]) for x in
-                     (RTOL * np.abs(t), C_TERM * EPS32 * mag, C_FLIP * flip, C_VJP * EPS32 * vjp, C_REF * row_ref)]
-            print(f"[grad {tag}] {name}: worst err/tol {worst[name]:.3f} (err {err.reshape(-1)[i]:.3e}; tol parts rtol "
-                  f"{parts[0]:.2e} term {parts[1]:.2e} flip {parts[2]:.2e} vjp {parts[3]:.2e} ref {parts[4]:.2e}); "
-                  f"elements with a flip allowance: {int((flip > 0).sum())}")
-        assert (err <= tol).all(), f"{name}: worst err/tol {worst[name]:.3f}, {(err > tol).sum()} elements over"
-        # end to end (oracle forward state): loose, the amplification is inherent to the reference's formulation
-        e2e = orc["grads"][name].astype(np.float64).reshape(a.shape)
-        s2 = np.abs(e2e).max() + 1e-30
-        slack = max(1.0, gpu.get("pixel_allowance_max", PIX_TOL) / PIX_TOL)  # ill-conditioned forward: its pixels move too
-        assert (np.abs(a - e2e) <= 2e-4 * np.abs(e2e) + 1e-3 * slack * s2 + 2.0 * C_FLIP * flip).all(), f"{name} end-to-end"  # flips: either forward state may have taken them
-        # dense and exactly zero for non-visible splats
-        vis = np.zeros(a.shape[0], bool)
-        vis[orc["aux"]["global_from_compact_gid"][:V]] = True
-        assert not a[~vis].any()
+    for leg, f64, f32_ref in (("shared", orc["grads_f64"], orc["grads_f32"]), ("e2e", orc["grads_f64_e2e"], orc["grads"])):
+        for name in GRAD_NAMES:
+            t = f64[name]
+            a = gpu[name].detach().cpu().numpy().astype(np.float64).reshape(t.shape)
+            ref_err = np.abs(f32_ref[name].astype(np.float64).reshape(t.shape) - t)
+            row_ref = _rowmax(ref_err, t.shape)
+            flip = f64["flip_" + name[2:]]
+            rec = {}
+            for key, consts in CANDIDATES.items():
+                ratio, err, parts = _grad_ratio(a, f64, row_ref, name, consts)
+                noflip = ratio[flip == 0] if ratio.size else ratio
+                rec[key] = dict(worst=float(ratio.max()) if ratio.size else 0.0,
+                                worst_noflip=float(noflip.max()) if noflip.size else 0.0)
+                if key == ACTIVE:
+                    active = (ratio, err, parts)
+            ratio, err, parts = active
+            i = int(np.argmax(ratio)) if ratio.size else 0
+            w = float(ratio.reshape(-1)[i]) if ratio.size else 0.0
+            worst[(leg, name)] = w
+            mag = f64["mag_" + name[2:]]
+            nz = (mag > 0) & (flip == 0)
+            units = float((err[nz] / (EPS32 * mag[nz])).max()) if nz.any() else 0.0
+            entry = dict(worst=w, units_eps_mag_noflip=units, candidates=rec, elements_with_flip=int((flip > 0).sum()))
+            if ratio.size:
+                pv = [float(np.broadcast_to(x, t.shape).reshape(-1)[i]) for x in parts]
+                entry.update(err=float(err.reshape(-1)[i]), parts=dict(rtol=pv[0], term=pv[1], flip=pv[2], vjp=pv[3], ref=pv[4]))
+                print(f"[grad {leg} {tag}] {name}: worst err/tol {w:.3f} (err {entry['err']:.3e}; tol parts rtol {pv[0]:.2e} "
+                      f"term {pv[1]:.2e} flip {pv[2]:.2e} vjp {pv[3]:.2e} ref {pv[4]:.2e}); max err/(eps mag) off the flip "
+                      f"elements {units:.1f}; " + " ".join(f"{k}:{v['worst']:.2f}/{v['worst_noflip']:.2f}" for k, v in rec.items()))
+            M.record("grad_" + leg, name, entry)
+            assert (ratio <= 1.0).all(), f"{leg} {name}: worst err/tol {w:.3f}, {(ratio > 1.0).sum()} elements over"
+            M.check_growth("grad_" + leg, name, w)
+            if leg == "shared":
+                # dense and exactly zero for non-visible splats
+                vis = np.zeros(a.shape[0], bool)
+                vis[orc["aux"]["global_from_compact_gid"][:V]] = True
+                assert not a[~vis].any()
     return worst
 
 
@@ -451,7 +536,7 @@ def test_headline_size_matches_oracle(dev):
     integer state bit-exact, pixels and gradients within the stated tolerances, against the oracle."""
     cloud = H.synthetic_cloud(1 << 20, 3, seed=4, mean_mult=1.0)
     gpu, orc = _run_pair(dev, cloud, 1920, 1080, 3)
-    V, I = _assert_forward_parity(gpu, orc, 1920, 1080)
+    V, I = _assert_forward_parity(gpu, orc, 1920, 1080, named=True)
     _risk_report(orc, "S1")
     assert V > 100000 and I > 400000
     # splats that cover the whole 120x68 tile grid sum 8160 float-atomic partials in unspecified order:
@@ -473,7 +558,7 @@ def test_s4_sizes_match_oracle(dev, n, w, h, deg):
     """SURVEY §8(d) S4, the c1- and c2-sized synthetic stand-ins (no .ply / NeRF-synthetic data exists here)."""
     cloud = H.synthetic_cloud(n, deg, seed=4, mean_mult=1.0)
     gpu, orc = _run_pair(dev, cloud, w, h, deg)
-    V, I = _assert_forward_parity(gpu, orc, w, h)
+    V, I = _assert_forward_parity(gpu, orc, w, h, named=True)
     _risk_report(orc, f"S4 {n}@{w}x{h}")
     assert V > 5000 and I > V
     _assert_grad_parity(gpu, orc)
@@ -491,7 +576,7 @@ def test_c3_scale_raised_cap(dev, c3_cloud):
     """c3 with room for every intersection (max_intersects 40 M): integer state bit-exact, pixels and all six
     gradients against the oracle."""
     gpu, orc = _run_pair(dev, c3_cloud, 1920, 1080, 3, max_intersects=40_000_000)
-    V, I = _assert_forward_parity(gpu, orc, 1920, 1080)
+    V, I = _assert_forward_parity(gpu, orc, 1920, 1080, named=True)
     _risk_report(orc, "c3 raised cap")
     assert V > 300_000 and I >= 20_000_000 and int(gpu["aux"].overflow.item()) == 0
     _assert_grad_parity(gpu, orc)
@@ -503,7 +588,7 @@ def test_c3_scale_reference_cap_overflows(dev, c3_cloud):
     aux.overflow and stays bit-exact with the oracle run at that capacity."""
     gpu, orc = _run_pair(dev, c3_cloud, 1920, 1080, 3)
     assert gpu["aux"].max_intersects == 128 * 65535
-    V, I = _assert_forward_parity(gpu, orc, 1920, 1080)
+    V, I = _assert_forward_parity(gpu, orc, 1920, 1080, named=True)
     assert I == 8_388_480 and int(gpu["aux"].overflow.item()) == 1 and orc["aux"]["overflow"]
     _assert_grad_parity(gpu, orc)
 
