@@ -273,24 +273,37 @@ def main():
         eager_ms = timed(wl.fwd_bwd, args.steps, 2) * 1e3 / args.steps
 
     # ---- per-stage device time (hipEvents on the op's stream), separate untimed steps ----
-    stage_ms = {}
-    with StageProfiler() as prof:
-        acc = None
-        for _ in range(max(1, args.profile_steps)):
-            wl.fwd_bwd()  # eager: events cannot be recorded inside a replayed graph
-            ms = prof.read_ms()
-            acc = ms if acc is None else {k: acc[k] + ms[k] for k in ms}
-        stage_ms = {k: v / max(1, args.profile_steps) for k, v in acc.items()}
-    dominant = max(("rasterize", "rasterize_bwd", "project_bwd", "project_visible"), key=lambda k: stage_ms[k])
-    dom_bytes = stage_bytes(dominant, n, V, I, P, T, C)
-    achieved = dom_bytes / (stage_ms[dominant] * 1e-3) / 1e9 if stage_ms[dominant] > 0 else 0.0
+    def profile_stages(workload, steps):
+        """Mean stage times (ms) of `steps` eager fwd+bwd passes with hipEvents recorded on the op's stream after every
+        stage (brush_profiler_*): events cannot be recorded inside a replayed graph."""
+        with StageProfiler() as prof:
+            acc = None
+            for _ in range(max(1, steps)):
+                workload.fwd_bwd()
+                ms = prof.read_ms()
+                acc = ms if acc is None else {k: acc[k] + ms[k] for k in ms}
+        return {k: v / max(1, steps) for k, v in acc.items()}
+
+    def dominant_roofline(st_ms, nn, VV, II, PP, TT, CC):
+        """`roofline` object of the single-kernel stage that takes the longest: algorithmic bytes per launch (SURVEY
+        §8d accounting, stage_bytes) / its live event time, against the HBM peak."""
+        dom = max(("rasterize", "rasterize_bwd", "project_bwd", "project_visible"), key=lambda k: st_ms[k])
+        nbytes = stage_bytes(dom, nn, VV, II, PP, TT, CC)
+        ach = nbytes / (st_ms[dom] * 1e-3) / 1e9 if st_ms[dom] > 0 else 0.0
+        return dom, nbytes, ach
+
+    stage_ms = profile_stages(wl, args.profile_steps)
+    dominant, dom_bytes, achieved = dominant_roofline(stage_ms, n, V, I, P, T, C)
     traffic, valu, traffic_src = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    tj = {}
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(dominant)
-            traffic_src = f"profiles/traffic.json ({tj.get('_tag', 'static')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not re-measured in this run"
+            traffic_src = (f"profiles/traffic.json (tag {tj.get('_tag', 'static')}, taken at commit {tj.get('_commit', '?')}): "
+                           "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (tools/profile_gpu.sh), not "
+                           "re-measured in this run")
             insts = tj.get("valu_insts", {}).get(dominant)
             if insts and stage_ms[dominant] > 0:
                 # The ceiling that binds the compositing kernels (DESIGN.md §4): VALU issue.  Measured with
@@ -364,6 +377,9 @@ def main():
     if world == 1 and not args.no_extra:
         extra = {}
         todo = [("dense_scene", dict(n=n, w=w, h=h, deg=deg, mean_mult=0.25, cap=None, steps=20)),
+                # BASELINE config 3 ("full sort/composite stress"): 3 M splats packed until the frame saturates,
+                # 27 M intersections = 3.2x the reference's cap, so the capacity is raised (tests: test_c3_scale_raised_cap)
+                ("c3", dict(n=3_000_000, w=w, h=h, deg=deg, mean_mult=0.12, cap=40_000_000, steps=6)),
                 ("S3", dict(n=20_971_520, w=3840, h=2160, deg=deg, mean_mult=1.0, cap=24_000_000, steps=6))]
         if (n, w, h, args.mean_mult) != (1 << 20, 1920, 1080, 1.0):
             todo = []
@@ -379,11 +395,20 @@ def main():
                 torch.cuda.synchronize()
                 Vx, Ix = ax.read_num_visible(), ax.read_num_intersections()
                 Px, Tx = c["w"] * c["h"], (-(-c["w"] // 16)) * (-(-c["h"] // 16))
-                Bx = algorithmic_bytes(c["n"], Vx, Ix, Px, Tx, (c["deg"] + 1) ** 2)
+                Cx = (c["deg"] + 1) ** 2
+                Bx = algorithmic_bytes(c["n"], Vx, Ix, Px, Tx, Cx)
+                st = profile_stages(x, 3)
+                dom, dbytes, ach = dominant_roofline(st, c["n"], Vx, Ix, Px, Tx, Cx)
                 extra[name] = {"workload": f"{c['n']} splats @{c['w']}x{c['h']}, SH degree {c['deg']}, mean_mult {c['mean_mult']}",
                                "ms_per_step": round(sec * 1e3 / c["steps"], 4), "num_visible": Vx, "num_intersections": Ix,
-                               "overflow": int(ax.overflow.item()), "algorithmic_bytes": int(Bx),
-                               "frac_of_hbm_peak": round(Bx / (sec / c["steps"]) / 1e9 / HBM_PEAK_GBS, 5)}
+                               "max_intersects": ax.max_intersects, "overflow": int(ax.overflow.item()),
+                               "algorithmic_bytes": int(Bx),
+                               "frac_of_hbm_peak": round(Bx / (sec / c["steps"]) / 1e9 / HBM_PEAK_GBS, 5),
+                               "stage_ms": {k: round(v, 5) for k, v in st.items()},
+                               "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                                            "algorithmic_bytes": int(dbytes), "kernel_ms": round(st[dom], 5),
+                                            "traffic": tj.get("extra", {}).get(name, {}).get(dom)}}
                 del x, pp, ax
                 torch.cuda.empty_cache()
             except Exception as e:  # an extra line must never take the headline down

@@ -60,6 +60,7 @@ class BrushAdamConfig(C.Structure):
         ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float),
         ("time", C.c_uint32),
         ("rotation_grad_wrt_normalized", C.c_uint32),
+        ("xy_stat_scale", C.c_float),  # batch_views for view-sharded steps (0 = 1)
     ]
 
 
@@ -105,7 +106,7 @@ _SYMBOLS = [
       C.c_size_t, _P]),
     ("brush_view_index_size", C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
     ("brush_reduce_view_records", C.c_int,
-     [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+     [_P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     ("brush_loss_workspace_size", C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
     ("brush_l1_ssim_loss", C.c_int,
      [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_float, _P, _P, _P, C.c_size_t, _P]),
@@ -115,7 +116,7 @@ _SYMBOLS = [
      [C.POINTER(BrushUniforms), C.POINTER(BrushAux), C.POINTER(BrushAdamConfig), _P, _P, _P, _P, _P, _P, C.c_uint32,
       _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     ("brush_reduce_view_records_adam", C.c_int,
-     [_P, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(BrushAdamConfig), C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P,
+     [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(BrushAdamConfig), C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P,
       C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     ("brush_normalize_quats", C.c_int, [_P, _P, C.c_uint32, _P]),
     ("brush_refine_stats", C.c_int,

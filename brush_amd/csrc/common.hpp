@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/brush_hip.h"
 
 namespace brush {
@@ -36,6 +38,15 @@ void set_last_hip_error(int e);
             return BRUSH_ERR_HIP;                               \
         }                                                       \
     } while (0)
+
+// Per-device caches (function attributes, SIMD counts) are keyed on the CURRENT device of the calling thread: slot
+// of that device in a small table (devices beyond it share the last slot, whose entries are then re-derived per call).
+constexpr int kMaxDevices = 64;
+static inline int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < kMaxDevices ? dev : kMaxDevices - 1;
+}
 
 static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

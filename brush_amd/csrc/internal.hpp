@@ -61,6 +61,7 @@ struct AdamFuse {
     float *norm_rot_out;                                   // optional [N,4]: updated rotation / |rotation| (next forward's input)
     float *grad_2d_accum, *xy_grad_counts;                 // optional [N]: refinement statistics (train.rs:284-316)
     float half_w, half_h;
+    float stat_scale;                                      // BrushAdamConfig::xy_stat_scale (0 -> 1)
 };
 // Deterministic mode: where a splat's compact-order sums come from (see project_bwd.hip); partials == nullptr
 // selects the default atomic accumulators in v_compact.
@@ -85,7 +86,8 @@ hipError_t launch_project_backward_records(const ViewParams &vp, const float *me
                                            const uint32_t *global_from_compact, const float *v_compact,
                                            float *records, uint32_t max_rows, const DetSumsArgs &det, hipStream_t s);
 hipError_t launch_reduce_view_records(const float *records, uint32_t num_views, uint32_t rows_per_view,
-                                      const uint32_t *view_rows, const float *campos, const float *means, uint32_t n,
+                                      const uint32_t *view_rows, const uint32_t *view_offsets /* nullable */,
+                                      const float *campos, const float *means, uint32_t n,
                                       uint32_t sh_degree, uint32_t *index, float *v_means, float *v_scales,
                                       float *v_quats, float *v_sh, float *v_opac, const AdamFuse *adam, hipStream_t s);
 hipError_t launch_zero_compact_grads(const uint32_t *num_visible, uint32_t n, float *v_compact, hipStream_t s);

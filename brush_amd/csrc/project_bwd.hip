@@ -319,7 +319,7 @@ __device__ __forceinline__ void store_gradients_or_step(
                 reinterpret_cast<float4 *>(af.norm_rot_out)[g_own] = make_float4(r.x / s, r.y / s, r.z / s, r.w / s);
             }
             if (af.grad_2d_accum) {  // train.rs:284-316
-                af.grad_2d_accum[g_own] += stat_norm;
+                af.grad_2d_accum[g_own] += stat_norm * af.stat_scale;
                 if (stat_count != 0.0f) af.xy_grad_counts[g_own] += stat_count;
             }
             af.raw_opac[g_own] = adam_elem(af, 10 * nn + g_own, o_opac, af.raw_opac[g_own], af.lr[3]);
@@ -658,14 +658,19 @@ __global__ __launch_bounds__(kThreads) void k_project_backward_records(
 // check of an entry nobody wrote this step costs no gather.
 __global__ __launch_bounds__(kThreads) void k_build_view_index(const float4 *__restrict__ records, uint32_t num_views,
                                                                uint32_t rows_per_view,
-                                                               const uint32_t *__restrict__ view_rows, uint32_t n,
+                                                               const uint32_t *__restrict__ view_rows,
+                                                               const uint32_t *__restrict__ view_offsets, uint32_t n,
                                                                uint32_t *__restrict__ index) {
-    const uint32_t total = num_views * rows_per_view;
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < total; i += gridDim.x * kThreads) {
-        const uint32_t v = i / rows_per_view, r = i - v * rows_per_view;
-        if (r >= view_rows[v]) continue;
-        const uint32_t gid = __float_as_uint(records[(size_t)i * (kRecFloats / 4)].x);
-        if (gid < n) index[(size_t)v * n + gid] = r;
+    // view_offsets == nullptr: view v owns rows [v * rows_per_view, + view_rows[v]); otherwise the views are packed,
+    // view v owns rows [view_offsets[v], + view_rows[v]) of a buffer of rows_per_view rows in all.
+    for (uint32_t v = 0; v < num_views; v++) {  // uniform: a handful of views
+        const uint32_t first = view_offsets ? view_offsets[v] : v * rows_per_view;
+        const uint32_t room = view_offsets ? (first < rows_per_view ? rows_per_view - first : 0u) : rows_per_view;
+        const uint32_t cnt = min(view_rows[v], room);
+        for (uint32_t r = blockIdx.x * kThreads + threadIdx.x; r < cnt; r += gridDim.x * kThreads) {
+            const uint32_t gid = __float_as_uint(records[(size_t)(first + r) * (kRecFloats / 4)].x);
+            if (gid < n) index[(size_t)v * n + gid] = r;
+        }
     }
 }
 
@@ -679,31 +684,55 @@ struct ViewSums {
 template <int DEG, typename AddSh>
 __device__ __forceinline__ void sum_view_records(const float4 *__restrict__ records, uint32_t num_views,
                                                  uint32_t rows_per_view, const uint32_t *__restrict__ view_rows,
+                                                 const uint32_t *__restrict__ view_offsets,
                                                  const float *__restrict__ campos, uint32_t *__restrict__ index,
                                                  const float *means, uint32_t n, uint32_t g, ViewSums &o, AddSh add_sh) {
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
+    constexpr uint32_t kChunk = 8;  // views whose index entries / record heads are in flight together
     const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
-    for (uint32_t v = 0; v < num_views; v++) {
-        const uint32_t r = index[(size_t)v * n + g];
-        if (r >= min(view_rows[v], rows_per_view)) continue;
-        const float4 *rec = records + ((size_t)v * rows_per_view + r) * (kRecFloats / 4);
-        const float4 a = rec[0];
-        if (__float_as_uint(a.x) != g) continue;  // stale index entry
-        index[(size_t)v * n + g] = kInvalid;
-        const float4 b = rec[1], c = rec[2], d = rec[3];
-        o.mean[0] += a.y, o.mean[1] += a.z, o.mean[2] += a.w;
-        o.scale[0] += b.x, o.scale[1] += b.y, o.scale[2] += b.z;
-        o.quat[0] += b.w, o.quat[1] += c.x, o.quat[2] += c.y, o.quat[3] += c.z;
-        o.opac += c.w;
-        o.stat_norm += d.w;
-        o.stat_count += 1.0f;
-        // gather_grads.wgsl:182-222 with this view's camera term (viewmat[3].xyz)
-        float dir[3] = {mean[0] - campos[v * 3], mean[1] - campos[v * 3 + 1], mean[2] - campos[v * 3 + 2]};
-        const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-        dir[0] = dir[0] / len, dir[1] = dir[1] / len, dir[2] = dir[2] / len;
-        float Y[ncoef];
-        sh_basis<ncoef>(DEG, dir, Y);
-        add_sh(Y, d);
+    for (uint32_t v0 = 0; v0 < num_views; v0 += kChunk) {
+        // One memory phase for the index entries of up to 8 views, one for the heads of the records they point to
+        // (round 2 walked the views one by one: two dependent loads per view, 117 us at 8 views where one view takes 43),
+        // then the sums in view order: the same bits on every rank.
+        uint32_t r[kChunk];
+#pragma unroll
+        for (uint32_t j = 0; j < kChunk; j++) r[j] = v0 + j < num_views ? index[(size_t)(v0 + j) * n + g] : kInvalid;
+        const float4 *rec[kChunk];
+        float4 a[kChunk];
+#pragma unroll
+        for (uint32_t j = 0; j < kChunk; j++) {
+            const uint32_t v = v0 + j;
+            rec[j] = nullptr;
+            a[j] = make_float4(__uint_as_float(kInvalid), 0.f, 0.f, 0.f);
+            if (v < num_views) {
+                const uint32_t first = view_offsets ? view_offsets[v] : v * rows_per_view;
+                const uint32_t room = view_offsets ? (first < rows_per_view ? rows_per_view - first : 0u) : rows_per_view;
+                if (r[j] < min(view_rows[v], room)) {
+                    rec[j] = records + ((size_t)first + r[j]) * (kRecFloats / 4);
+                    a[j] = rec[j][0];
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kChunk; j++) {
+            const uint32_t v = v0 + j;
+            if (rec[j] == nullptr || __float_as_uint(a[j].x) != g) continue;  // no entry / stale index entry
+            index[(size_t)v * n + g] = kInvalid;
+            const float4 b = rec[j][1], c = rec[j][2], d = rec[j][3];
+            o.mean[0] += a[j].y, o.mean[1] += a[j].z, o.mean[2] += a[j].w;
+            o.scale[0] += b.x, o.scale[1] += b.y, o.scale[2] += b.z;
+            o.quat[0] += b.w, o.quat[1] += c.x, o.quat[2] += c.y, o.quat[3] += c.z;
+            o.opac += c.w;
+            o.stat_norm += d.w;
+            o.stat_count += 1.0f;
+            // gather_grads.wgsl:182-222 with this view's camera term (viewmat[3].xyz)
+            float dir[3] = {mean[0] - campos[v * 3], mean[1] - campos[v * 3 + 1], mean[2] - campos[v * 3 + 2]};
+            const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            dir[0] = dir[0] / len, dir[1] = dir[1] / len, dir[2] = dir[2] / len;
+            float Y[ncoef];
+            sh_basis<ncoef>(DEG, dir, Y);
+            add_sh(Y, d);
+        }
     }
 }
 
@@ -711,8 +740,8 @@ __device__ __forceinline__ void sum_view_records(const float4 *__restrict__ reco
 template <int DEG>
 __global__ __launch_bounds__(kThreads) void k_reduce_view_records_adam(
     const float4 *__restrict__ records, uint32_t num_views, uint32_t rows_per_view,
-    const uint32_t *__restrict__ view_rows, const float *__restrict__ campos, uint32_t *__restrict__ index,
-    const float *means, uint32_t n, AdamFuse af) {
+    const uint32_t *__restrict__ view_rows, const uint32_t *__restrict__ view_offsets,
+    const float *__restrict__ campos, uint32_t *__restrict__ index, const float *means, uint32_t n, AdamFuse af) {
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
     constexpr uint32_t kRow = ncoef * 3, kRowPad = kRow | 1u;
     constexpr uint32_t kStageFloats = (kWave * kRowPad > 512u ? kWave * kRowPad : 512u);
@@ -727,7 +756,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_view_records_adam(
 #pragma unroll
     for (uint32_t k = 0; k < kRow; k++) row[k] = 0.f;
     if (g < n)
-        sum_view_records<DEG>(records, num_views, rows_per_view, view_rows, campos, index, means, n, g, o,
+        sum_view_records<DEG>(records, num_views, rows_per_view, view_rows, view_offsets, campos, index, means, n, g, o,
                               [&](const float *Y, const float4 &d) {
 #pragma unroll
                                   for (uint32_t k = 0; k < ncoef; k++) {
@@ -747,8 +776,9 @@ __global__ __launch_bounds__(kThreads) void k_reduce_view_records_adam(
 template <int DEG>
 __global__ __launch_bounds__(kThreads) void k_reduce_view_records_dense(
     const float4 *__restrict__ records, uint32_t num_views, uint32_t rows_per_view,
-    const uint32_t *__restrict__ view_rows, const float *__restrict__ campos, uint32_t *__restrict__ index,
-    const float *means, uint32_t n, float *__restrict__ v_means, float *__restrict__ v_scales,
+    const uint32_t *__restrict__ view_rows, const uint32_t *__restrict__ view_offsets,
+    const float *__restrict__ campos, uint32_t *__restrict__ index, const float *means, uint32_t n,
+    float *__restrict__ v_means, float *__restrict__ v_scales,
     float *__restrict__ v_quats, float *__restrict__ v_sh, float *__restrict__ v_opac) {
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
     constexpr uint32_t kRow = ncoef * 3;
@@ -761,7 +791,8 @@ __global__ __launch_bounds__(kThreads) void k_reduce_view_records_dense(
 #pragma unroll
     for (uint32_t k = 0; k < kRow; k++) row[k] = 0.f;
     if (g < n)
-        sum_view_records<DEG>(records, num_views, rows_per_view, view_rows, campos, index, means, n, (uint32_t)g, o,
+        sum_view_records<DEG>(records, num_views, rows_per_view, view_rows, view_offsets, campos, index, means, n,
+                              (uint32_t)g, o,
                               [&](const float *Y, const float4 &d) {
 #pragma unroll
                                   for (uint32_t k = 0; k < ncoef; k++) {
@@ -844,24 +875,25 @@ hipError_t launch_project_backward_records(const ViewParams &vp, const float *me
 }
 
 hipError_t launch_reduce_view_records(const float *records, uint32_t num_views, uint32_t rows_per_view,
-                                      const uint32_t *view_rows, const float *campos, const float *means, uint32_t n,
+                                      const uint32_t *view_rows, const uint32_t *view_offsets, const float *campos,
+                                      const float *means, uint32_t n,
                                       uint32_t sh_degree, uint32_t *index, float *v_means, float *v_scales,
                                       float *v_quats, float *v_sh, float *v_opac, const AdamFuse *adam, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const float4 *rec4 = reinterpret_cast<const float4 *>(records);
     if (num_views * rows_per_view > 0)
-        hipLaunchKernelGGL(k_build_view_index, dim3(min(ceil_div(num_views * rows_per_view, kThreads), 2048u)),
-                           dim3(kThreads), 0, s, rec4, num_views, rows_per_view, view_rows, n, index);
+        hipLaunchKernelGGL(k_build_view_index, dim3(min(ceil_div(rows_per_view, kThreads), 2048u)), dim3(kThreads), 0, s,
+                           rec4, num_views, rows_per_view, view_rows, view_offsets, n, index);
     const dim3 grid(ceil_div(n, kThreads)), block(kThreads);
     AdamFuse af{};
     if (adam) af = *adam;
 #define BRUSH_LAUNCH_RV(D)                                                                                         \
     if (adam)                                                                                                      \
         hipLaunchKernelGGL((k_reduce_view_records_adam<D>), grid, block, 0, s, rec4, num_views, rows_per_view,     \
-                           view_rows, campos, index, means, n, af);                                                \
+                           view_rows, view_offsets, campos, index, means, n, af);                                  \
     else                                                                                                           \
         hipLaunchKernelGGL((k_reduce_view_records_dense<D>), grid, block, 0, s, rec4, num_views, rows_per_view,    \
-                           view_rows, campos, index, means, n, v_means, v_scales, v_quats, v_sh, v_opac)
+                           view_rows, view_offsets, campos, index, means, n, v_means, v_scales, v_quats, v_sh, v_opac)
     switch (sh_degree) {
         case 0: BRUSH_LAUNCH_RV(0); break;
         case 1: BRUSH_LAUNCH_RV(1); break;

@@ -387,16 +387,19 @@ SortWs carve_sort(void *ws, uint32_t max_n) {
     return w;
 }
 
-// The downsweep needs more LDS than the 64 KiB a kernel gets by default: opt in once per process.
+// The downsweep needs more LDS than the 64 KiB a kernel gets by default: opt in once per DEVICE (the attribute
+// belongs to the function's instance on the current device; an embedder may drive several devices from one process).
 hipError_t enable_big_lds() {
-    static const hipError_t st = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLds));
-        if (e != hipSuccess) return e;
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep_big),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLdsBig));
-    }();
-    return st;
+    static std::atomic<int> done[kMaxDevices];
+    const int dev = current_device_slot();
+    if (done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLds));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep_big),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLdsBig));
+    if (e == hipSuccess) done[dev].store(1, std::memory_order_release);
+    return e;
 }
 
 }  // namespace

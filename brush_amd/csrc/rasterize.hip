@@ -559,13 +559,17 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
     // round (1080p: 8160 waves on 1024 SIMDs, k = 4 -> 2 rounds, 152 us; k = 5 -> 1.6 rounds, 164 us; k = 3: 177 us).
     // The registers allow up to 5; fewer are enforced with unused dynamic LDS per workgroup.  Workgroups of 4 waves
     // (4 tiles in a row): 1, 2 and 8 measured slower (154 / 157 / 172 vs 142 us).
-    static const uint32_t simds = [] {
+    static std::atomic<uint32_t> simds_of[kMaxDevices];  // per device (0 = not queried yet)
+    const int slot = current_device_slot();
+    uint32_t simds = simds_of[slot].load(std::memory_order_relaxed);
+    if (simds == 0u || slot == kMaxDevices - 1) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        return (uint32_t)cus * 4u;
-    }();
+        simds = (uint32_t)cus * 4u;
+        simds_of[slot].store(simds, std::memory_order_relaxed);
+    }
     auto lds_pad_for = [&](uint32_t units, uint32_t max_k) -> uint32_t {
         uint32_t best_k = max_k, best_cost = 0xFFFFFFFFu;
         for (uint32_t k = max_k; k >= 3u; k--) {

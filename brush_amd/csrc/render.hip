@@ -362,6 +362,7 @@ static bool fill_adam_fuse(const BrushAdamConfig *cfg, float *means, float *log_
     af.norm_rot_out = next_quats_fed;
     af.grad_2d_accum = grad_2d_accum, af.xy_grad_counts = xy_grad_counts;
     af.half_w = (float)w / 2.0f, af.half_h = (float)h / 2.0f;
+    af.stat_scale = cfg->xy_stat_scale > 0.0f ? cfg->xy_stat_scale : 1.0f;
     af.vec_ok = (n % 4 == 0) && aligned(means) && aligned(log_scales) && aligned(sh) && aligned(moment1) &&
                 aligned(moment2);
     *out = af;
@@ -431,7 +432,8 @@ extern "C" int brush_view_index_size(uint32_t n, uint32_t num_views, size_t *byt
 }
 
 static int reduce_views_impl(const float *records, uint32_t num_views, uint32_t rows_per_view, const uint32_t *view_rows,
-                             const float *campos, const float *means, uint32_t n, uint32_t sh_degree, float *v_means,
+                             const uint32_t *view_offsets, const float *campos, const float *means, uint32_t n,
+                             uint32_t sh_degree, float *v_means,
                              float *v_scales, float *v_quats, float *v_sh, float *v_opac, const AdamFuse *adam,
                              void *view_index, size_t view_index_bytes, brush_stream_t stream) {
     if (sh_degree > 4 || num_views == 0) return BRUSH_ERR_INVALID_ARG;
@@ -440,24 +442,26 @@ static int reduce_views_impl(const float *records, uint32_t num_views, uint32_t 
     if ((reinterpret_cast<uintptr_t>(records) & 15) != 0) return BRUSH_ERR_INVALID_ARG;
     if (!adam && (!v_means || !v_scales || !v_quats || !v_sh || !v_opac)) return BRUSH_ERR_INVALID_ARG;
     if (view_index_bytes < sizeof(uint32_t) * (size_t)n * num_views) return BRUSH_ERR_WORKSPACE_SMALL;
-    if ((uint64_t)num_views * rows_per_view > 0xFFFFFFFFull) return BRUSH_ERR_INVALID_ARG;
-    BRUSH_HIP_CHECK(launch_reduce_view_records(records, num_views, rows_per_view, view_rows, campos, means, n, sh_degree,
+    if (!view_offsets && (uint64_t)num_views * rows_per_view > 0xFFFFFFFFull) return BRUSH_ERR_INVALID_ARG;
+    BRUSH_HIP_CHECK(launch_reduce_view_records(records, num_views, rows_per_view, view_rows, view_offsets, campos, means, n,
+                                               sh_degree,
                                                static_cast<uint32_t *>(view_index), v_means, v_scales, v_quats, v_sh,
                                                v_opac, adam, static_cast<hipStream_t>(stream)));
     return BRUSH_OK;
 }
 
 extern "C" int brush_reduce_view_records(const float *records, uint32_t num_views, uint32_t rows_per_view,
-                                         const uint32_t *view_rows, const float *campos, const float *means,
-                                         uint32_t n, uint32_t sh_degree, float *v_means, float *v_scales,
-                                         float *v_quats, float *v_sh, float *v_opac, void *view_index,
+                                         const uint32_t *view_rows, const uint32_t *view_offsets, const float *campos,
+                                         const float *means, uint32_t n, uint32_t sh_degree, float *v_means,
+                                         float *v_scales, float *v_quats, float *v_sh, float *v_opac, void *view_index,
                                          size_t view_index_bytes, brush_stream_t stream) {
-    return reduce_views_impl(records, num_views, rows_per_view, view_rows, campos, means, n, sh_degree, v_means,
+    return reduce_views_impl(records, num_views, rows_per_view, view_rows, view_offsets, campos, means, n, sh_degree, v_means,
                              v_scales, v_quats, v_sh, v_opac, nullptr, view_index, view_index_bytes, stream);
 }
 
 extern "C" int brush_reduce_view_records_adam(const float *records, uint32_t num_views, uint32_t rows_per_view,
-                                              const uint32_t *view_rows, const float *campos,
+                                              const uint32_t *view_rows, const uint32_t *view_offsets,
+                                              const float *campos,
                                               const BrushAdamConfig *cfg, uint32_t width, uint32_t height,
                                               float *means, float *log_scales, float *rotation, float *raw_opacity,
                                               float *sh, uint32_t n, uint32_t sh_degree, float *moment1, float *moment2,
@@ -467,7 +471,8 @@ extern "C" int brush_reduce_view_records_adam(const float *records, uint32_t num
     if (!fill_adam_fuse(cfg, means, log_scales, rotation, raw_opacity, sh, n, moment1, moment2, next_quats_fed,
                         grad_2d_accum, xy_grad_counts, width, height, &af))
         return BRUSH_ERR_INVALID_ARG;
-    return reduce_views_impl(records, num_views, rows_per_view, view_rows, campos, means, n, sh_degree, nullptr, nullptr,
+    return reduce_views_impl(records, num_views, rows_per_view, view_rows, view_offsets, campos, means, n, sh_degree,
+                             nullptr, nullptr,
                              nullptr, nullptr, nullptr, &af, view_index, view_index_bytes, stream);
 }
 

@@ -128,20 +128,22 @@ def records_from_dense_torch(grads: dict, aux: RenderAux, n: int, img_size, rows
     return rec
 
 
-def reduce_view_records_torch(recs: torch.Tensor, view_rows: torch.Tensor, campos: torch.Tensor, means: torch.Tensor,
+def reduce_view_records_torch(recs, view_rows: torch.Tensor, campos: torch.Tensor, means: torch.Tensor,
                               n: int, ncoef: int) -> dict:
     """Plain-torch restatement of brush_reduce_view_records: dense sum over views, accumulated in view order
-    (every rank that runs this on the same bytes gets the same bits)."""
-    W, rows, _ = recs.shape
-    dev = recs.device
+    (every rank that runs this on the same bytes gets the same bits).  `recs`: [W, rows, 16] (padded form) or a
+    list of W per-view [rows_v, 16] tensors (packed form, what ViewExchange.gather returns by default)."""
+    W = len(recs)
+    rows = None if isinstance(recs, (list, tuple)) else recs.shape[1]
+    dev = recs[0].device
     degree = int(round(ncoef ** 0.5)) - 1
     out = {"v_means": torch.zeros((n, 3), device=dev), "v_scales": torch.zeros((n, 3), device=dev),
            "v_quats": torch.zeros((n, 4), device=dev), "v_opac": torch.zeros((n,), device=dev),
            "v_sh": torch.zeros((n, ncoef, 3), device=dev), "xy_norm": torch.zeros((n,), device=dev),
            "views_seen": torch.zeros((n,), device=dev)}
     for v in range(W):
-        cnt = min(int(view_rows[v]), rows)
-        r = recs[v, :cnt]
+        cnt = min(int(view_rows[v]), recs[v].shape[0] if rows is None else rows)
+        r = recs[v][:cnt]
         gid = r[:, 0].contiguous().view(torch.int32).long()
         keep = (gid >= 0) & (gid < n)
         r, gid = r[keep], gid[keep]
@@ -174,8 +176,13 @@ class ViewExchange:
         grads = xchg.reduce_dense(means)   or   xchg.reduce_adam(cfg, params..., moments...)
     """
 
-    def __init__(self, n: int, ncoef: int, device, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, n: int, ncoef: int, device, group: Optional[dist.ProcessGroup] = None, packed: bool = True):
         self.n, self.ncoef, self.device, self.group = int(n), int(ncoef), torch.device(device), group
+        # packed: the all-gather moves exactly num_visible records per view (sum over views) and the reduction reads
+        # them through per-view row offsets; False: every view padded to the largest (W x max), one plain all_gather
+        self.packed = bool(packed)
+        self._offsets_dev = None
+        self._offsets_pinned = None
         self.degree = int(round(ncoef ** 0.5)) - 1
         live = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if live else 1
@@ -261,8 +268,42 @@ class ViewExchange:
         self.local[:rec.shape[0]].copy_(rec)
 
     # -- exchange ------------------------------------------------------------------------------
-    def gather(self) -> torch.Tensor:
-        """All-gather of exactly padded(max count) rows per view.  Returns the [W, rows, 16] records."""
+    def _gather_packed(self, counts):
+        """Exact sizes: view v's count[v] records land at row offset sum(count[:v]) of the flat buffer.  RCCL takes the
+        uneven all_gather as grouped broadcasts; gloo (CPU rehearsal) gets one broadcast per view."""
+        offs = [0]
+        for c in counts[:-1]:
+            offs.append(offs[-1] + int(c))
+        total = offs[-1] + int(counts[-1])
+        flat = self.gathered[:max(total, 1) * _REC]
+        slices = [flat[offs[r] * _REC:(offs[r] + int(counts[r])) * _REC] for r in range(self.world)]
+        mine = self.local[:int(counts[self.rank])].reshape(-1)
+        if self.world > 1:
+            backend = dist.get_backend(self.group)
+            if backend == "nccl" and all(int(c) > 0 for c in counts):
+                dist.all_gather(slices, mine, group=self.group)
+            else:
+                slices[self.rank].copy_(mine)
+                for r in range(self.world):
+                    if int(counts[r]) > 0:
+                        dist.broadcast(slices[r], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                       group=self.group)
+        else:
+            slices[0].copy_(mine)
+        if self.device.type == "cuda":
+            if self._offsets_pinned is None:
+                self._offsets_pinned = torch.empty(self.world, dtype=torch.int32, pin_memory=True)
+                self._offsets_dev = torch.empty(self.world, dtype=torch.int32, device=self.device)
+            self._offsets_pinned.copy_(torch.tensor(offs, dtype=torch.int32))
+            self._offsets_dev.copy_(self._offsets_pinned, non_blocking=True)
+        else:
+            self._offsets_dev = torch.tensor(offs, dtype=torch.int32)
+        self._rows = total
+        return [s_.view(-1, _REC) for s_ in slices]
+
+    def gather(self):
+        """All-gather of this step's records.  packed (default): exactly count[v] rows per view, returned as a list of
+        W [count_v, 16] views of one flat buffer; padded: padded(max count) rows per view, returned as [W, rows, 16]."""
         counts = self.counts()
         need = max(counts) if counts else 0
         if need > self.capacity:  # a view grew by more than the headroom since the buffer was sized: redo its records
@@ -270,6 +311,8 @@ class ViewExchange:
             self._ensure_capacity(need)
             if getattr(self, "_bwd_args", None) is not None:
                 self.backward_records(*self._bwd_args)
+        if self.packed:
+            return self._gather_packed(counts)
         rows = min(_padded_rows(need), self.capacity)
         self._rows = rows
         out = self.gathered[:self.world * rows * _REC]
@@ -293,10 +336,16 @@ class ViewExchange:
             # all-ones = "no row": the reduction clears what it consumes, so the buffer never holds stale entries
             self.n = int(n)
             self.index = torch.full((nbytes.value,), 0xFF, dtype=torch.uint8, device=self.device)
-        recs = self.gathered[:self.world * self._rows * _REC]
+        if self.packed:
+            recs = self.gathered[:max(self._rows, 1) * _REC]
+        else:
+            recs = self.gathered[:self.world * self._rows * _REC]
         view_rows = self.metas[:, 0].contiguous()
         campos = self.metas[:, 1:4].contiguous().view(torch.float32)
         return recs, view_rows, campos, nbytes.value
+
+    def _offsets_ptr(self):
+        return self._offsets_dev.data_ptr() if self.packed else None
 
     def reduce_dense(self, means: torch.Tensor, block: Optional[torch.Tensor] = None):
         """Sum over views into the dense gradient block (brush_reduce_view_records).  Returns (grads, block);
@@ -310,8 +359,8 @@ class ViewExchange:
         recs, view_rows, campos, ibytes = self._reduce_common(n)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().brush_reduce_view_records(
-                recs.data_ptr(), self.world, self._rows, view_rows.data_ptr(), campos.data_ptr(), means.data_ptr(), n,
-                self.degree, _seg_ptr(block, layout, "v_means"), _seg_ptr(block, layout, "v_scales"),
+                recs.data_ptr(), self.world, self._rows, view_rows.data_ptr(), self._offsets_ptr(), campos.data_ptr(),
+                means.data_ptr(), n, self.degree, _seg_ptr(block, layout, "v_means"), _seg_ptr(block, layout, "v_scales"),
                 _seg_ptr(block, layout, "v_quats"), _seg_ptr(block, layout, "v_sh"), _seg_ptr(block, layout, "v_opac"),
                 self.index.data_ptr(), ibytes, torch.cuda.current_stream().cuda_stream), "brush_reduce_view_records")
         self._keep = (view_rows, campos)  # alive until the kernel has run
@@ -337,7 +386,8 @@ class ViewExchange:
         ptr = lambda t: None if t is None else t.data_ptr()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().brush_reduce_view_records_adam(
-                recs.data_ptr(), self.world, self._rows, view_rows.data_ptr(), campos.data_ptr(), C.byref(cfg),
+                recs.data_ptr(), self.world, self._rows, view_rows.data_ptr(), self._offsets_ptr(), campos.data_ptr(),
+                C.byref(cfg),
                 int(img_size[0]), int(img_size[1]), means.data_ptr(), log_scales.data_ptr(), rotation.data_ptr(),
                 raw_opacity.data_ptr(), sh.data_ptr(), n, self.degree, moment1.data_ptr(), moment2.data_ptr(),
                 ptr(next_quats_fed), ptr(grad_2d_accum), ptr(xy_grad_counts), self.index.data_ptr(), ibytes,

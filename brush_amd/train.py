@@ -236,7 +236,10 @@ class SplatTrainer:
             pre_step = {"means": means.clone(), "rotation": quats.clone(), "sh": sh.clone(), "opac": raw_opac.clone(),
                         "scales": log_scales.clone()}
         cfg = _lib.BrushAdamConfig(self._lr_mean(scene_extent), c.lr_scale, c.lr_rotation, c.lr_opac,
-                                   c.lr_coeffs_dc, 1.0 / c.lr_coeffs_sh_scale, 0.9, 0.999, 1e-15, self.opt_time + 1, 1)
+                                   c.lr_coeffs_dc, 1.0 / c.lr_coeffs_sh_scale, 0.9, 0.999, 1e-15, self.opt_time + 1, 1,
+                                   # v_pred carries 1/batch_views: keep the densification statistic at the magnitude the
+                                   # reference's threshold was tuned for (batch 1, train.rs:284-316)
+                                   float(batch_views))
         want_stats = self.iter > c.warmup_steps  # housekeeping, train.rs:284-316
         with torch.cuda.device(means.device):
             if exchange is not None:
@@ -280,7 +283,7 @@ class SplatTrainer:
                         from .dist import densification_stats
                         stats = densification_stats(v_xy, aux, (w, h))
                         allreduce_densification_stats(stats)
-                        self.grad_2d_accum += stats[0]
+                        self.grad_2d_accum += stats[0] * float(batch_views)  # undo the 1/batch of the loss scale
                         self.xy_grad_counts += stats[1]
                     else:
                         s_aux = aux._as_struct()

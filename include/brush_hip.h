@@ -203,14 +203,18 @@ int brush_render_backward_records(const BrushUniforms *h_uniforms, const BrushAu
  * without a gather.  No reset between steps. */
 int brush_view_index_size(uint32_t n, uint32_t num_views, size_t *bytes);
 /* Sum over views -> dense gradients.  records: [num_views][rows_per_view][16]; view v owns its first
- * view_rows[v] rows (device array [num_views], values > rows_per_view are clamped); campos: [num_views][3] =
+ * view_rows[v] rows (device array [num_views], values > rows_per_view are clamped).  view_offsets (device array
+ * [num_views], or NULL): when given the views are PACKED — view v owns rows [view_offsets[v], + view_rows[v]) of a
+ * buffer of rows_per_view rows in all — which is what an all-gather of exactly num_visible records per view leaves
+ * (the padded form moves num_views x the largest view).  campos: [num_views][3] =
  * viewmat[3].xyz of each view (the term the reference uses as camera position, project_visible.wgsl:232-233);
  * means: [N,3].  Every element of v_means [N,3] v_scales [N,3] v_quats [N,4] v_sh [N,C,3] v_opac [N] is written
  * (0 for splats no view sees). */
 int brush_reduce_view_records(const float *records, uint32_t num_views, uint32_t rows_per_view,
-                              const uint32_t *view_rows, const float *campos, const float *means, uint32_t n,
-                              uint32_t sh_degree, float *v_means, float *v_scales, float *v_quats, float *v_sh,
-                              float *v_opac, void *view_index, size_t view_index_bytes, brush_stream_t stream);
+                              const uint32_t *view_rows, const uint32_t *view_offsets, const float *campos,
+                              const float *means, uint32_t n, uint32_t sh_degree, float *v_means, float *v_scales,
+                              float *v_quats, float *v_sh, float *v_opac, void *view_index, size_t view_index_bytes,
+                              brush_stream_t stream);
 
 /* ---- training iteration around the op (build extension) -------------------- */
 /* The reference's SplatTrainer::step (crates/brush-train/src/train.rs:211-393) wraps the op in
@@ -239,6 +243,11 @@ typedef struct BrushAdamConfig {
      * (what Splats::render feeds the op, gaussian_splats.rs:174-175); the chain rule through the
      * normalisation is applied before the moment update.  0: v_quats is used as is. */
     uint32_t rotation_grad_wrt_normalized;
+    /* Multiplies the screen-space statistic |v_xy * (w/2, h/2)| before it is added to grad_2d_accum (fused forms only).
+     * With B views per step the upstream gradient carries the 1/B of the mean over the batch (train.rs:239-268), so the
+     * statistic the densification threshold is compared with (train.rs:284-316, tuned for B = 1) would shrink B-fold:
+     * pass B here to keep the reference's magnitude.  0 is read as 1. */
+    float xy_stat_scale;
 } BrushAdamConfig;
 /* One Adam step on all five parameter groups in one launch.  v_*: the gradient arrays of
  * brush_render_backward; moment1 / moment2: N*(11+3C) floats each, owned by the caller, laid out
@@ -272,7 +281,8 @@ int brush_render_backward_adam(const BrushUniforms *uniforms, const BrushAux *au
  * [N] += sum over views of the record's |v_xy * (w/2, h/2)| / number of views that saw the splat
  * (train.rs:284-316 for a batch of views). */
 int brush_reduce_view_records_adam(const float *records, uint32_t num_views, uint32_t rows_per_view,
-                                   const uint32_t *view_rows, const float *campos, const BrushAdamConfig *cfg,
+                                   const uint32_t *view_rows, const uint32_t *view_offsets, const float *campos,
+                                   const BrushAdamConfig *cfg,
                                    uint32_t width, uint32_t height, float *means, float *log_scales, float *rotation,
                                    float *raw_opacity, float *sh, uint32_t n, uint32_t sh_degree, float *moment1,
                                    float *moment2, float *next_quats_fed, float *grad_2d_accum, float *xy_grad_counts,

@@ -105,11 +105,11 @@ def test_gradients_are_bitwise_reproducible_and_modes_coexist(dev):
     x = BD.ViewExchange(n, C, dev)
     x.begin(aux)
     x.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, v_out)
-    r1 = x.gather().clone()
+    r1 = x.gather()[0].clone()
     x.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, v_out)
-    r2 = x.gather().clone()
+    r2 = x.gather()[0].clone()
     V = aux.read_num_visible()
-    assert torch.equal(r1[0, :V], r2[0, :V])
+    assert r1.shape[0] == V and torch.equal(r1, r2)
     grads, red = x.reduce_dense(p["means"])
     layout, _ = R.grad_block_layout(n, C)
     for name in ("v_means", "v_scales", "v_quats", "v_opac"):

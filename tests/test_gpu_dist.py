@@ -66,15 +66,17 @@ def _worker(rank, world, port, q):
             torch.cuda.synchronize()
             got = red[:pf].detach().cpu()
             # the HIP record kernel against the torch restatement fed with the HIP dense gradients
-            want_rec = BD.records_from_dense_torch(g, aux, n, (w, h), recs.shape[1])
             V = aux.read_num_visible()
-            rec_err = float((recs[rank, :V, 1:].double() - want_rec[:V, 1:].double()).abs().max()
+            mine = recs[rank]  # packed form: exactly V rows of this view, at row offset sum of the counts before it
+            assert mine.shape[0] == V and sum(r.shape[0] for r in recs) == sum(xchg.counts())
+            want_rec = BD.records_from_dense_torch(g, aux, n, (w, h), V)
+            rec_err = float((mine[:V, 1:].double() - want_rec[:V, 1:].double()).abs().max()
                             / (want_rec[:V, 1:].abs().max() + 1e-30))
-            gid_ok = bool(torch.equal(recs[rank, :V, 0].contiguous().view(torch.int32),
+            gid_ok = bool(torch.equal(mine[:V, 0].contiguous().view(torch.int32),
                                       want_rec[:V, 0].contiguous().view(torch.int32)))
             results.append(dict(step=step, V=V, err=float((got.double() - dense.double()).abs().max()),
                                 scale=float(dense.abs().max()), rec_err=rec_err, gid_ok=gid_ok,
-                                regrown=xchg.regrown, rows=int(recs.shape[1]), red=got.numpy()))
+                                regrown=xchg.regrown, rows=int(xchg._rows), red=got.numpy()))
         # fused form: the same records straight into Adam == brush_adam_step on the reduced dense gradients
         params = {k: p[k].clone() for k in ("means", "log_scales", "quats", "raw_opac", "sh")}
         m1 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
@@ -142,3 +144,73 @@ def test_record_exchange_two_ranks_one_gpu():
         assert np.array_equal(got[0][3][k].view(np.uint32), got[1][3][k].view(np.uint32)), k
     assert np.array_equal(got[0][4], got[1][4]) and np.array_equal(got[0][5], got[1][5])
     assert got[0][5].max() == 2.0 and got[0][4].max() > 0
+
+
+def _refine_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import brush_amd
+        from brush_amd import dist as BD
+
+        dev = torch.device("cuda:0")
+        n, w, h, deg = 6000, 160, 96, 1
+        ncoef = (deg + 1) ** 2
+        cloud = H.synthetic_cloud(n, deg, seed=8, mean_mult=0.002)
+        splats = brush_amd.Splats(*(torch.from_numpy(cloud[k]).to(dev) for k in ("means", "sh", "quats", "raw_opac",
+                                                                                  "log_scales")))
+        c = H.reference_test_camera(w, h)
+        cam = brush_amd.Camera([0.4 * rank, -0.2 * rank, -8.0], c["rotation_xyzw"], c["fov_x"], c["fov_y"], c["center_uv"])
+        torch.manual_seed(5 + rank)
+        gt = torch.rand((h, w, 3), device=dev)
+        # refinement every 3 steps with a threshold low enough that it clones / splits / prunes at once
+        cfg = brush_amd.TrainConfig(warmup_steps=0, refine_every=3, densify_grad_thresh=1e-7, max_refine_step=100)
+        trainer = brush_amd.SplatTrainer(splats, cfg)
+        xchg = BD.ViewExchange(n, ncoef, dev)
+        counts, refines = [], []
+        for _ in range(8):
+            trainer.step(splats, cam, gt, 1.0, world, None, xchg)
+            counts.append(splats.num_splats())
+            if trainer.last_refine is not None:
+                r = trainer.last_refine
+                refines.append((r.num_split, r.num_cloned, r.num_transparent_pruned, r.num_scale_pruned))
+        torch.cuda.synchronize()
+        q.put((rank, counts, refines, xchg.n,
+               {k: getattr(splats, k).detach().cpu().numpy() for k in ("means", "sh_coeffs", "rotation", "raw_opacity",
+                                                                       "log_scales")},
+               trainer.moment1.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_exchange_survives_refinement_two_ranks_one_gpu():
+    """The splat count changes under a running ViewExchange (refine_splats clones / splits / prunes, train.rs:395-579):
+    the reduction takes its count, its moment offsets and its [view][n] index from the PARAMETERS of each call, so the
+    steps after a refinement update every splat of the new cloud, and both ranks still hold the same bits."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_refine_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=500)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts, refines, xn, params, m1 = got[0]
+    assert len(refines) >= 2 and any(sum(r) > 0 for r in refines), refines
+    assert len(set(counts)) > 1, counts              # the cloud really changed size ...
+    assert xn == counts[-1] == params["means"].shape[0]  # ... and the exchange followed it
+    assert got[1][0] == counts and got[1][1] == refines
+    for k in params:
+        assert np.array_equal(params[k].view(np.uint32), got[1][3][k].view(np.uint32)), k
+        assert np.isfinite(params[k]).all()
+    assert np.array_equal(m1.view(np.uint32), got[1][4].view(np.uint32))
+    assert m1.shape[0] == counts[-1] * (11 + 3 * 4)  # moments laid out for the refined cloud

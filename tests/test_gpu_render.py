@@ -295,9 +295,12 @@ def _assert_forward_parity(gpu, orc, w, h, saturation_flip_frac=0.0, named=False
 #                                                 differ in the last bits, so its noise is a different sample of it.
 #                + C_REF rowmax|oracle_f32 - f64| the error the f32 restatement of the reference makes on this row
 # The constants are CALIBRATED, not guessed: every run evaluates the candidate sets below and records each one's worst
-# err/tol per test and tensor (profiles/parity_margins.json); the active set is the tightest whose worst ratio over the
-# elements WITHOUT a flip allowance stays <= 1/4 on every test of the suite in both modes (i.e. each constant is at most
-# 4x what was ever observed).  On top of the allowance, no test's worst ratio may grow past 2x its tracked value
+# err/tol per test and tensor (profiles/parity_margins.json).  Measured over the whole suite in both modes: with
+# (C_TERM, C_DEPTH, C_VJP, C_REF) = (8, 1, 8, 1) the worst ratio over the elements WITHOUT a flip allowance is 0.24 on
+# every test whose scene the reference itself can run (each constant at most 4x what was ever observed; round 2 used
+# (64, -, 16, 4)); the 20 M-splat 4K frame (c5: lists 556 entries deep, beyond the reference's limits) needs C_DEPTH = 2
+# (1.06 with 1), so 2 it is: no-flip worst 0.69 there.  On top of the allowance, no test's worst ratio may grow past 2x
+# its tracked value
 # (tests/margins.py): a kernel change that makes the gradients several times less accurate turns the suite red even
 # though it still fits the mechanism-based bound (BRUSH_INJECT_VVA_ULPS build, tests/test_gpu_gate.py).
 RTOL, C_FLIP = 1e-4, 1.5
@@ -310,8 +313,10 @@ CANDIDATES = {                      # (C_TERM, C_DEPTH, C_VJP, C_REF)
     "e": (8.0, 1.0, 8.0, 0.0),
     "f": (4.0, 0.25, 4.0, 1.0),
     "g": (8.0, 0.25, 8.0, 1.0),
+    "h": (8.0, 2.0, 8.0, 1.0),
+    "i": (4.0, 2.0, 4.0, 1.0),
 }
-ACTIVE = "a"
+ACTIVE = "h"
 C_TERM, C_DEPTH, C_VJP, C_REF = CANDIDATES[ACTIVE]
 GRAD_NAMES = ("v_means", "v_scales", "v_quats", "v_sh", "v_opac", "v_xy")
 
@@ -774,9 +779,10 @@ def test_view_records_round_trip(dev, deg):
     xchg = BD.ViewExchange(n, C, dev)
     xchg.begin(aux)
     xchg.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, v_out)
-    recs = xchg.gather()
-    assert recs.shape[0] == 1 and recs.shape[1] >= V and xchg.counts() == [V]
-    want = BD.records_from_dense_torch(g, aux, n, (w, h), recs.shape[1])
+    recs = xchg.gather()  # packed form: a list with one [V, 16] view of the flat buffer per view
+    assert len(recs) == 1 and recs[0].shape[0] == V and xchg.counts() == [V]
+    recs = recs[0].unsqueeze(0)  # [1, V, 16] view of the same memory
+    want = BD.records_from_dense_torch(g, aux, n, (w, h), V)
     assert torch.equal(recs[0, :V, 0].contiguous().view(torch.int32), want[:V, 0].contiguous().view(torch.int32))
     # everything but v_rgb is the same arithmetic on the same compact sums (float atomics: two backward runs differ
     # in the last bits), v_rgb differs from v_sh0 / Y0 by one rounding
@@ -804,8 +810,10 @@ def test_view_records_round_trip(dev, deg):
     assert not bool(grads2["v_means"][dropped].any())  # records whose gid is out of range are ignored, entries re-validated
 
 
-def test_view_records_many_views(dev):
-    """Five views of one cloud on one GPU, their records laid out as the all-gather would leave them: the HIP reduction
+@pytest.mark.parametrize("packed", [True, False])
+def test_view_records_many_views(dev, packed):
+    """Five views of one cloud on one GPU, their records laid out as the all-gather would leave them (packed: view after
+    view at exact sizes with row offsets; padded: every view at the stride of the largest): the HIP reduction
     (dense form) adds a splat's records in view order exactly like the torch restatement (bit for bit for the per-splat
     vectors, v_sh to rounding), twice in a row on the same index buffer (entries consumed by the first call are gone,
     the second rebuilds them), and splats no view sees get exact zeros."""
@@ -834,18 +842,29 @@ def test_view_records_many_views(dev):
         x.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, v_out)
         recs = x.gather()
         V = aux.read_num_visible()
-        assert V > 500
+        assert V > 500 and recs[0].shape[0] == V
         seen[aux.global_from_compact_gid[:V].long()] = True
-        views.append((recs[0, :V].clone(), x.metas.clone()))
+        views.append((recs[0].clone(), x.metas.clone()))
     rows = max(v[0].shape[0] for v in views)
-    x = BD.ViewExchange(n, C, dev)
+    x = BD.ViewExchange(n, C, dev, packed=packed)
     x.world = W
     x.metas = torch.cat([v[1] for v in views], 0).contiguous()
     x._ensure_capacity(rows)
-    x._rows = rows
-    g = x.gathered[:W * rows * 16].view(W, rows, 16)
-    for i, v in enumerate(views):
-        g[i, :v[0].shape[0]] = v[0]
+    if packed:
+        counts = [v[0].shape[0] for v in views]
+        offs = [sum(counts[:i]) for i in range(W)]
+        x._rows = sum(counts)
+        x._offsets_dev = torch.tensor(offs, dtype=torch.int32, device=dev)
+        flat = x.gathered[:x._rows * 16].view(-1, 16)
+        g = []
+        for i, v in enumerate(views):
+            flat[offs[i]:offs[i] + counts[i]] = v[0]
+            g.append(flat[offs[i]:offs[i] + counts[i]])
+    else:
+        x._rows = rows
+        g = x.gathered[:W * rows * 16].view(W, rows, 16)
+        for i, v in enumerate(views):
+            g[i, :v[0].shape[0]] = v[0]
     ref = BD.reduce_view_records_torch(g, x.metas[:, 0], x.metas[:, 1:4].contiguous().view(torch.float32), p["means"], n, C)
     for rep in range(2):
         grads, _ = x.reduce_dense(p["means"])
