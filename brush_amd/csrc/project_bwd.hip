@@ -472,6 +472,10 @@ __device__ __forceinline__ void zero_invisible_rows(uint32_t n, uint32_t g0, uin
 // gradients are never written to nor re-read from HBM.  v_xy is still stored (refinement statistics).
 // In this mode `means`/`log_scales`/`raw_opac` alias the parameters being updated: each lane reads
 // its own splat before the wave writes the same 64 splats, and no other wave touches them.
+// (Measured and rejected, round 3: handing the 13 small-array results of a visible splat back through LDS to the lane
+// that owns the splat, so that v_means / v_xy / v_scales / v_quats / v_opac leave as whole cache lines, zeros and values
+// together: 1.48 vs 1.39 ms at 21 M splats, 52.2 vs 51.7 us at 1 M.  The extra barrier costs more than the partial
+// lines.)
 template <int DEG, bool ADAM>
 __global__ __launch_bounds__(kThreads) void k_project_backward(
     ViewParams vp, const float *means, const float *log_scales, const float *__restrict__ quats,

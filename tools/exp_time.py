@@ -61,15 +61,19 @@ for r in range(8):
                                                                       p["raw_opac"], Cc, out, v_out, blk)), 1)
 res["visible_per_view"] = [v[2] for v in views]
 for W in (1, 2, 4, 8):
+    # the packed layout the exact-size all-gather leaves: view after view, row offsets on the device
     rows = max(v[0].shape[0] for v in views[:W])
+    counts = [v[0].shape[0] for v in views[:W]]
+    offs = [sum(counts[:i]) for i in range(W)]
     x = BD.ViewExchange(n, Cc, dev)
     x.world = W
     x.metas = torch.cat([v[1] for v in views[:W]], 0).contiguous()
     x._ensure_capacity(rows)
-    x._rows = rows
-    g = x.gathered[:W * rows * 16].view(W, rows, 16)
+    x._rows = sum(counts)
+    x._offsets_dev = torch.tensor(offs, dtype=torch.int32, device=dev)
+    flat = x.gathered[:x._rows * 16].view(-1, 16)
     for i, v in enumerate(views[:W]):
-        g[i, :v[0].shape[0]] = v[0]
+        flat[offs[i]:offs[i] + counts[i]] = v[0]
     blk = torch.empty(R.grad_block_layout(n, Cc)[1], device=dev)
     res[f"reduce_dense_W{W}_us"] = round(t_us(lambda: x.reduce_dense(p["means"], blk)), 1)
     prm = {k: v.clone() for k, v in p.items()}
@@ -80,7 +84,8 @@ for W in (1, 2, 4, 8):
     cfg = _lib.BrushAdamConfig(1.6e-4, 0.01, 0.002, 0.05, 0.004, 0.05, 0.9, 0.999, 1e-15, 1, 1)
     res[f"reduce_adam_W{W}_us"] = round(t_us(lambda: x.reduce_adam(cfg, (w, h), prm["means"], prm["log_scales"], prm["quats"],
                                                                    prm["raw_opac"], prm["sh"], m1, m2, nxt, acc, cnt)), 1)
-    res[f"gathered_MB_per_rank_W{W}"] = round((W - 1) * rows * 64 / 1e6, 2)
+    res[f"gathered_MB_per_rank_W{W}"] = round((sum(counts) - counts[0]) * 64 / 1e6, 2)
+    res[f"gathered_MB_per_rank_padded_W{W}"] = round((W - 1) * rows * 64 / 1e6, 2)
 print(json.dumps(res))
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=1)
