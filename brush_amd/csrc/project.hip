@@ -76,17 +76,83 @@ __device__ __forceinline__ uint32_t walk_inline_count(const uint32_t bb[4], cons
     return cnt;
 }
 
+// ---- two-phase tile test (splat_math.hpp: tile_test_head / tile_test_tail) --------------------------------------------
+// Every candidate tile gets the cheap head at once; the ~18 % whose head returns kTileEdge wait in a per-wave LDS ring
+// with their geometry until 64 of them are there, then the expensive tail runs on a full wave and its hits are OR-ed
+// into the owner's late-hit words.  The owner adds them to its hit mask when the walk is over.
+constexpr uint32_t kLateRing = 128;  // < 64 waiting + <= 64 pushed per step
+struct LateRing {
+    float4 a[kLateRing];  // q0 q1 q2 centre.x
+    float4 b[kLateRing];  // centre.y | tx + (ty << 16) | owner lane + (bit << 8) | -
+    uint32_t lo[kWave], hi[kWave];  // late hits of the mask owned by lane l
+};
+struct LateState {
+    uint32_t head, count;  // wave-uniform
+};
+__device__ __forceinline__ void late_reset(LateRing &R, LateState &st) {
+    R.lo[lane_id()] = 0u;
+    R.hi[lane_id()] = 0u;
+    st.head = st.count = 0u;
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void late_run(LateRing &R, uint32_t first, uint32_t n) {
+    const uint32_t lane = lane_id();
+    if (lane < n) {
+        const uint32_t e = (first + lane) & (kLateRing - 1u);
+        const float4 a = R.a[e], b = R.b[e];
+        const float q[3] = {a.x, a.y, a.z};
+        const float c[2] = {a.w, b.x};
+        const uint32_t t = __float_as_uint(b.y), dst = __float_as_uint(b.z);
+        if (tile_test_tail(q, t & 0xFFFFu, t >> 16, c)) {
+            const uint32_t owner = dst & 0xFFu, bit = dst >> 8;
+            atomicOr(bit < 32u ? &R.lo[owner] : &R.hi[owner], 1u << (bit & 31u));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// Must be called by all 64 lanes.  `edge`: this lane's candidate needs the tail.
+__device__ __forceinline__ void late_push(LateRing &R, LateState &st, bool edge, const float q[3], const float c[2],
+                                          uint32_t tx, uint32_t ty, uint32_t owner, uint32_t bit) {
+    const uint64_t m = __ballot(edge);
+    if (m == 0ull) return;  // wave-uniform
+    if (edge) {
+        const uint32_t e = (st.head + st.count + __popcll(m & lanemask_lt())) & (kLateRing - 1u);
+        R.a[e] = make_float4(q[0], q[1], q[2], c[0]);
+        R.b[e] = make_float4(c[1], __uint_as_float(tx | (ty << 16)), __uint_as_float(owner | (bit << 8)), 0.0f);
+    }
+    st.count += (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (st.count >= kWave) {
+        late_run(R, st.head, kWave);
+        st.head = (st.head + kWave) & (kLateRing - 1u);
+        st.count -= kWave;
+    }
+}
+// Runs what is left and returns this lane's late hits.
+__device__ __forceinline__ uint64_t late_flush(LateRing &R, LateState &st) {
+    if (st.count) late_run(R, st.head, st.count);
+    st.head = (st.head + st.count) & (kLateRing - 1u);
+    st.count = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t late = ((uint64_t)R.hi[lane_id()] << 32) | R.lo[lane_id()];
+    __builtin_amdgcn_wave_barrier();
+    return late;
+}
+
 // Wave-flattened walk of the wave's small bboxes.  `area` = this lane's bbox tile count (0 if the
 // lane has no small bbox).  Must be called by all 64 lanes.  Returns this lane's hit count and
 // its row-major hit mask.
 // `first` = row-major index (inside the lane's bbox) of the lane's first candidate: 0 for a whole
 // small bbox, k * kChunkTiles for chunk k of a queued one.
 __device__ __forceinline__ void walk_flat(uint32_t area, const uint32_t bb[4], const TileTest &tt, const float xy[2],
-                                          uint32_t first, uint32_t &cnt, uint64_t &mask) {
+                                          uint32_t first, uint32_t &cnt, uint64_t &mask, LateRing &ring) {
     const uint32_t lane = lane_id();
     const uint32_t bw = bb[2] - bb[0];
     cnt = 0;
     mask = 0;
+    const TileReach reach = make_tile_reach(tt);
+    LateState st;
+    late_reset(ring, st);
     const uint32_t incl = wave_inclusive_scan(area);
     const uint32_t excl = incl - area;
     const uint32_t total = __shfl(incl, 63, 64);
@@ -106,21 +172,27 @@ __device__ __forceinline__ void walk_flat(uint32_t area, const uint32_t bb[4], c
         const float oxy[2] = {__shfl(xy[0], own, 64), __shfl(xy[1], own, 64)};
         const uint32_t ob0 = __shfl(bb[0], own, 64), ob1 = __shfl(bb[1], own, 64);
         const uint32_t obw = __shfl(bw, own, 64), oexcl = __shfl(excl, own, 64), ofirst = __shfl(first, own, 64);
-        bool hit = false;
+        TileReach orr;
+        orr.rx = __shfl(reach.rx, own, 64);
+        orr.ry = __shfl(reach.ry, own, 64);
+        uint32_t cls = kTileMiss, tx = 0, ty = 0;
         if (j < total) {
             const uint32_t li = ofirst + (j - oexcl);
-            hit = can_be_visible(ot, ob0 + li % obw, ob1 + li / obw, oxy);
+            tx = ob0 + li % obw, ty = ob1 + li / obw;
+            cls = tile_test_head(ot, orr, tx, ty, oxy);
         }
-        const uint64_t bal = __ballot(hit);
+        const uint64_t bal = __ballot(cls == kTileHit);
+        late_push(ring, st, cls == kTileEdge, ot.q, oxy, tx, ty, own, j - oexcl);
         // harvest: this lane's candidates occupy [excl, incl) of the flattened list
         const uint32_t lo = max(excl, base), hi = min(incl, base + kWave);
         if (lo < hi) {
             const uint32_t len = hi - lo;
             const uint64_t seg = (bal >> (lo - base)) & (len == 64 ? ~0ull : ((1ull << len) - 1ull));
-            cnt += __popcll(seg);
             mask |= seg << (lo - excl);
         }
     }
+    mask |= late_flush(ring, st);
+    cnt = (uint32_t)__popcll(mask);
 }
 
 __device__ __forceinline__ void walk_inline_emit(const uint32_t bb[4], const TileTest &tt, const float xy[2],
@@ -225,6 +297,10 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                                            uint32_t *__restrict__ walk_counter) {
     __shared__ uint32_t wave_cnt[kThreads / kWave];
     __shared__ uint32_t vis_list[kThreads / kWave][kCullPerThread * kWave];  // per wave: global ids that passed
+    // ... and their raw opacities: streamed with Phase A's coalesced loads (4 B per splat) instead of gathered in Phase B,
+    // where every candidate's 4 bytes cost a 128-byte request (measured at 21 M splats: 2.5 M such requests, 17 % of the
+    // kernel's memory traffic, profiles/r03_s3_stream_counters.json)
+    __shared__ float vis_opac[kThreads / kWave][kCullPerThread * kWave];
     const uint32_t gt = blockIdx.x * kThreads + threadIdx.x;
     if (gt < kUniformWords) uniforms_buffer[gt] = reinterpret_cast<const uint32_t *>(&u)[gt];
     if (gt == 0) {
@@ -242,7 +318,7 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
     // decision).  Only ~1 splat in 8 survives them, so the survivors' ids are queued per wave and the
     // expensive exact projection (Phase B) runs on full waves instead of once per round at 12 % lane
     // occupancy.  The loads of all four rounds are issued up front (one memory phase per wave).
-    float mean_r[kCullPerThread][3], smax_r[kCullPerThread];
+    float mean_r[kCullPerThread][3], smax_r[kCullPerThread], opac_r[kCullPerThread];
     const uint32_t last = vp.total_splats ? vp.total_splats - 1 : 0;
 #pragma unroll
     for (uint32_t r = 0; r < kCullPerThread; r++) {
@@ -251,13 +327,16 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
 #pragma unroll
             for (int k = 0; k < 3; k++) mean_r[r][k] = means[g * 3 + k];
             smax_r[r] = fmaxf(log_scales[g * 3], fmaxf(log_scales[g * 3 + 1], log_scales[g * 3 + 2]));
+            opac_r[r] = raw_opac[g];
         } else {
             mean_r[r][0] = mean_r[r][1] = mean_r[r][2] = 0.0f;
             smax_r[r] = 0.0f;
+            opac_r[r] = 0.0f;
         }
     }
     uint32_t n_cand = 0;
     uint32_t *list = vis_list[threadIdx.x / kWave];
+    float *list_opac = vis_opac[threadIdx.x / kWave];
 #pragma unroll
     for (uint32_t r = 0; r < kCullPerThread; r++) {
         const uint32_t g = blockIdx.x * kCullBlock + r * kThreads + threadIdx.x;
@@ -284,7 +363,11 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
             compact_from_global[g] = kInvalid;
         }
         const uint64_t bal = __ballot(maybe);
-        if (maybe) list[n_cand + __popcll(bal & lanemask_lt())] = g;
+        if (maybe) {
+            const uint32_t slot = n_cand + __popcll(bal & lanemask_lt());
+            list[slot] = g;
+            list_opac[slot] = opac_r[r];
+        }
         n_cand += __popcll(bal);
     }
     __builtin_amdgcn_wave_barrier();
@@ -302,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                     det_expf(log_scales[(size_t)g * 3 + 2])};
             const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
             const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-            const float ro = raw_opac[g];
+            const float ro = list_opac[i];
             const float *sh = sh_coeffs + (size_t)g * ((DEG + 1) * (DEG + 1)) * 3;
             float p_view[3], cov2d[3];
             to_view(vp, mean, p_view);
@@ -437,6 +520,7 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
     const uint32_t spw = V <= kHalfWaveSplats ? 32u : kWave;
     // Block-uniform trip count: the queue reservation below is a workgroup-level collective.
     __shared__ uint32_t wave_chunks[kThreads / kWave], block_base_s;
+    __shared__ LateRing rings[kThreads / kWave];
     const uint32_t wv = threadIdx.x / kWave;
     const uint32_t per_block = (kThreads / kWave) * spw;
     for (uint32_t bbase = blockIdx.x * per_block; bbase < V; bbase += gridDim.x * per_block) {
@@ -495,7 +579,7 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
         const bool small = active && bbox_tiles <= small_area;
         uint32_t flat_cnt;
         uint64_t flat_mask;
-        walk_flat(small ? bbox_tiles : 0u, bb, tt, xy, 0u, flat_cnt, flat_mask);
+        walk_flat(small ? bbox_tiles : 0u, bb, tt, xy, 0u, flat_cnt, flat_mask, rings[wv]);
         if (small) {
             area = flat_cnt;
             slot = kInlineFlag;
@@ -535,6 +619,8 @@ __device__ __forceinline__ float bcastf(float v, uint32_t src_lane) {
 // the group, from which the emit pass derives every item's output offset without a scan.
 __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const float *__restrict__ projected,
                                                          WalkQueue q, uint32_t *__restrict__ tiles_hit) {
+    __shared__ LateRing rings[kThreads / kWave];
+    LateRing &ring = rings[threadIdx.x / kWave];
     const uint32_t n_items = min(*q.counter, q.capacity);
     const uint32_t G = walk_group(n_items);
     const uint32_t n_groups = (n_items + G - 1) / G;
@@ -555,8 +641,10 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
         if (valid) s = load_walk(vp, projected, item.x);
         const uint32_t first = item.y * kChunkTiles;
         const uint32_t len = (valid && first < s.area) ? min(s.area - first, kChunkTiles) : 0u;
-        uint32_t my_cnt = 0;
         uint64_t my_mask = 0;
+        const TileReach reach = make_tile_reach(s.tt);
+        LateState st;
+        late_reset(ring, st);
         const uint32_t in_group = min(G, n_items - grp * G);
         for (uint32_t qi = 0; qi < in_group; qi++) {  // wave-uniform
             const uint32_t qlen = bcast(len, qi);
@@ -564,13 +652,19 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
             TileTest t;
             t.q[0] = bcastf(s.tt.q[0], qi), t.q[1] = bcastf(s.tt.q[1], qi), t.q[2] = bcastf(s.tt.q[2], qi);
             t.any = bcast((uint32_t)s.tt.any, qi) != 0u;
+            TileReach r;
+            r.rx = bcastf(reach.rx, qi), r.ry = bcastf(reach.ry, qi);
             const float xy[2] = {bcastf(s.xy[0], qi), bcastf(s.xy[1], qi)};
             const uint32_t b0 = bcast(s.b0, qi), b1 = bcast(s.b1, qi), bw = bcast(s.bw, qi);
             const uint32_t i = bcast(first, qi) + lane;
-            const bool hit = lane < qlen && can_be_visible(t, b0 + i % bw, b1 + i / bw, xy);
-            const uint64_t bal = __ballot(hit);
-            if (lane == qi) my_mask = bal, my_cnt = __popcll(bal);
+            const uint32_t tx = b0 + i % bw, ty = b1 + i / bw;
+            const uint32_t cls = lane < qlen ? tile_test_head(t, r, tx, ty, xy) : kTileMiss;
+            const uint64_t bal = __ballot(cls == kTileHit);
+            if (lane == qi) my_mask = bal;
+            late_push(ring, st, cls == kTileEdge, t.q, xy, tx, ty, qi, lane);
         }
+        my_mask |= late_flush(ring, st);
+        const uint32_t my_cnt = (uint32_t)__popcll(my_mask);
         const uint32_t pre = wave_inclusive_scan(lane < G ? my_cnt : 0u);
         if (mine) {
             q.chunk_count[it] = pre;

@@ -289,6 +289,64 @@ __device__ __forceinline__ bool can_be_visible(const TileTest &t, uint32_t tx, u
     return ellipse_intersects_aabb(tc, ext, xy, t.q);
 }
 
+// ---- the same test in two phases (tile walks) ----------------------------------------------------------------------
+// ellipse_intersects_aabb is ~25 instructions for its first two clauses (centre inside the box; nearest corner inside
+// the ellipse) and ~250 for the two check_edge() calls behind them (two square roots, four divisions).  Over the bbox
+// tiles of the bench scenes 50-57 % of the tests end in the first two clauses and another 23-32 % are tiles the ellipse
+// cannot reach at all, so the walks classify every candidate with the HEAD below and queue the ~18 % left for the TAIL,
+// which then runs on full waves.  Decisions are bit-identical to can_be_visible():
+//   * head: the function's own first two clauses, same expressions, same order -> kTileHit;
+//   * kTileMiss only when the tile box lies outside the axis-aligned bounding box of the ellipse
+//     d^T Q d <= 1 (half extents sqrt(q2 / det Q), sqrt(q0 / det Q)) by a margin of 0.1 % + 0.02 px: every point of
+//     both edge segments is then outside the ellipse by far more than the f32 rounding of check_edge's roots, so
+//     both calls return false.  Non-finite or non-positive-definite Q never takes this exit (rx = ry = +inf);
+//   * tail: exactly the two check_edge() calls.
+enum : uint32_t { kTileMiss = 0u, kTileHit = 1u, kTileEdge = 2u };
+struct TileReach {
+    float rx, ry;  // |centre - tile centre| beyond which the tile cannot be reached
+};
+__device__ __forceinline__ TileReach make_tile_reach(const TileTest &t) {
+    TileReach r;
+    const float dq = t.q[0] * t.q[2] - t.q[1] * t.q[1];
+    const float hx = sqrtf(t.q[2] / dq), hy = sqrtf(t.q[0] / dq);
+    const float half = (float)kTileWidth / 2.0f;
+    // det Q = q0 q2 - q1^2 cancels for elongated, tilted ellipses: its f32 error is ~eps q0 q2, so the extents are only
+    // trusted (to 1e-4, against a margin of 1e-3) while det Q >= q0 q2 / 1024; beyond that every tile takes the tail
+    // (found by tests/aux/tile_reach_check.c: 432 wrong exits in 2e8 random cases without this condition, 0 with it)
+    const bool ok = t.any && dq > 0.0f && t.q[0] > 0.0f && t.q[2] > 0.0f && dq * 1024.0f >= t.q[0] * t.q[2] &&
+                    hx < 3.0e37f && hy < 3.0e37f;  // NaN -> false
+    r.rx = ok ? hx * 1.001f + (half + 0.02f) : __builtin_inff();
+    r.ry = ok ? hy * 1.001f + (half + 0.02f) : __builtin_inff();
+    return r;
+}
+__device__ __forceinline__ uint32_t tile_test_head(const TileTest &t, const TileReach &r, uint32_t tx, uint32_t ty,
+                                                   const float center[2]) {
+    if (!t.any) return kTileMiss;
+    const float ext[2] = {(float)kTileWidth / 2.0f, (float)kTileWidth / 2.0f};
+    const float box_pos[2] = {(float)(tx * kTileWidth) + ext[0], (float)(ty * kTileWidth) + ext[1]};
+    const float d[2] = {center[0] - box_pos[0], center[1] - box_pos[1]};
+    if (fabsf(d[0]) <= ext[0] && fabsf(d[1]) <= ext[1]) return kTileHit;
+    const float sg[2] = {signf(d[0]), signf(d[1])};
+    const float nc[2] = {box_pos[0] + sg[0] * ext[0], box_pos[1] + sg[1] * ext[1]};
+    const float cp[2] = {nc[0] - center[0], nc[1] - center[1]};
+    float cq[2];
+    vq(cp, t.q, cq);
+    if (dot2(cq, cp) <= 1.0f) return kTileHit;
+    if (fabsf(d[0]) > r.rx || fabsf(d[1]) > r.ry) return kTileMiss;
+    return kTileEdge;
+}
+// The tail of ellipse_intersects_aabb for a tile whose head returned kTileEdge (its first two clauses are false).
+__device__ __forceinline__ bool tile_test_tail(const float q[3], uint32_t tx, uint32_t ty, const float center[2]) {
+    const float ext[2] = {(float)kTileWidth / 2.0f, (float)kTileWidth / 2.0f};
+    const float box_pos[2] = {(float)(tx * kTileWidth) + ext[0], (float)(ty * kTileWidth) + ext[1]};
+    const float d[2] = {center[0] - box_pos[0], center[1] - box_pos[1]};
+    const float sg[2] = {signf(d[0]), signf(d[1])};
+    const float nc[2] = {box_pos[0] + sg[0] * ext[0], box_pos[1] + sg[1] * ext[1]};
+    const float e1[2] = {nc[0] - sg[0] * 2.0f * ext[0], nc[1] - 0.0f};
+    const float e2[2] = {nc[0] - 0.0f, nc[1] - sg[1] * 2.0f * ext[1]};
+    return check_edge(nc, e1, center, q) || check_edge(nc, e2, center, q);
+}
+
 // Sloan SH basis, project_visible.wgsl:51-147 / gather_grads.wgsl:17-112.
 template <int MAXC>
 __device__ __forceinline__ void sh_basis(uint32_t degree, const float d[3], float Y[MAXC]) {
