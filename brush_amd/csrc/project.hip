@@ -48,9 +48,13 @@ constexpr uint32_t kSmallArea = 16;      // few visible splats (latency-bound la
 constexpr uint32_t kSmallAreaMany = 64;
 constexpr uint32_t kHalfWaveSplats = 1u << 18;  // up to this many visible splats a ProjectVisible wave takes 32 of them  // many visible splats (throughput-bound): everything one hit mask can hold
 constexpr uint32_t kChunkTiles = 64;   // one 64-bit hit mask per queue item
-constexpr uint32_t kWalkGroupMax = 16;  // queue items a consumer wave takes at a time when the queue is long
-// Few items: small groups (more waves, shorter serial chains); many items: amortise the memory phase.
-__device__ __forceinline__ uint32_t walk_group(uint32_t n_items) { return n_items <= 16384u ? 4u : kWalkGroupMax; }
+constexpr uint32_t kWalkGroupMax = 64;  // queue items a consumer wave takes at a time when the queue is very long
+// Few items: small groups (more waves, shorter serial chains); many items: amortise the memory phase and the per-item
+// set-up (record gather, log / sqrt / divisions of the tile test and the walk rectangle: ~300 instructions that only
+// the group's lanes execute, so a group of 16 runs them at a quarter of the wave).
+__device__ __forceinline__ uint32_t walk_group(uint32_t n_items) {
+    return n_items <= 16384u ? 4u : (n_items <= (1u << 18) ? 16u : kWalkGroupMax);
+}
 
 struct WalkQueue {
     uint32_t *counter;      // [1] items reserved so far (zeroed by the cull kernel)
@@ -74,6 +78,17 @@ __device__ __forceinline__ uint32_t walk_inline_count(const uint32_t bb[4], cons
         for (uint32_t tx = bb[0]; tx < bb[2]; tx++)
             if (can_be_visible(tt, tx, ty, xy)) cnt++;
     return cnt;
+}
+
+// Row / column of row-major index i in a rectangle `bw` tiles wide: i = row * bw + col.  The u32 division the compiler
+// emits is ~25 instructions; here one v_rcp_f32 estimate (i < 2^24 is exact in f32, so the estimate is off by at most
+// one) and an integer fix-up make it exact for every input the walks can produce.
+__device__ __forceinline__ void row_col(uint32_t i, uint32_t bw, uint32_t &row, uint32_t &col) {
+    int32_t q = (int32_t)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bw));
+    int32_t r = (int32_t)i - q * (int32_t)bw;
+    if (r < 0) q -= 1, r += (int32_t)bw;
+    else if (r >= (int32_t)bw) q += 1, r -= (int32_t)bw;
+    row = (uint32_t)q, col = (uint32_t)r;
 }
 
 // ---- two-phase tile test (splat_math.hpp: tile_test_head / tile_test_tail) --------------------------------------------
@@ -178,7 +193,9 @@ __device__ __forceinline__ void walk_flat(uint32_t area, const uint32_t bb[4], c
         uint32_t cls = kTileMiss, tx = 0, ty = 0;
         if (j < total) {
             const uint32_t li = ofirst + (j - oexcl);
-            tx = ob0 + li % obw, ty = ob1 + li / obw;
+            uint32_t row, col;
+            row_col(li, obw, row, col);
+            tx = ob0 + col, ty = ob1 + row;
             cls = tile_test_head(ot, orr, tx, ty, oxy);
         }
         const uint64_t bal = __ballot(cls == kTileHit);
@@ -211,7 +228,8 @@ __device__ __forceinline__ void walk_inline_emit(const uint32_t bb[4], const Til
 struct SplatWalk {
     float xy[2];
     TileTest tt;
-    uint32_t b0, b1, bw, area;
+    TileReach reach;
+    uint32_t b0, b1, bw, area;  // the walk rectangle (splat_math.hpp: walk_rect)
 };
 __device__ __forceinline__ SplatWalk load_walk(const ViewParams &vp, const float *__restrict__ projected, uint32_t c) {
     const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
@@ -219,10 +237,10 @@ __device__ __forceinline__ SplatWalk load_walk(const ViewParams &vp, const float
     s.xy[0] = p[0];
     s.xy[1] = p[1];
     const float conic[3] = {p[2], p[3], p[4]};
-    const uint32_t radius = radius_from_conic(conic);
     uint32_t bb[4];
-    get_tile_bbox(s.xy, radius, vp.tile_bounds, bb);
     s.tt = make_tile_test(conic, p[8]);
+    s.reach = make_tile_reach(s.tt);
+    walk_rect(s.xy, conic, s.tt, s.reach, vp.tile_bounds, bb);
     s.b0 = bb[0];
     s.b1 = bb[1];
     s.bw = bb[2] - bb[0];
@@ -297,10 +315,8 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                                            uint32_t *__restrict__ walk_counter) {
     __shared__ uint32_t wave_cnt[kThreads / kWave];
     __shared__ uint32_t vis_list[kThreads / kWave][kCullPerThread * kWave];  // per wave: global ids that passed
-    // ... and their raw opacities: streamed with Phase A's coalesced loads (4 B per splat) instead of gathered in Phase B,
-    // where every candidate's 4 bytes cost a 128-byte request (measured at 21 M splats: 2.5 M such requests, 17 % of the
-    // kernel's memory traffic, profiles/r03_s3_stream_counters.json)
-    __shared__ float vis_opac[kThreads / kWave][kCullPerThread * kWave];
+    // (Measured and rejected, round 3: streaming the raw opacities with Phase A's coalesced loads instead of gathering
+    // them in Phase B, where every candidate's 4 bytes cost a 128-byte request: +1.5 us at 1 M splats, no gain at 21 M.)
     const uint32_t gt = blockIdx.x * kThreads + threadIdx.x;
     if (gt < kUniformWords) uniforms_buffer[gt] = reinterpret_cast<const uint32_t *>(&u)[gt];
     if (gt == 0) {
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
     // decision).  Only ~1 splat in 8 survives them, so the survivors' ids are queued per wave and the
     // expensive exact projection (Phase B) runs on full waves instead of once per round at 12 % lane
     // occupancy.  The loads of all four rounds are issued up front (one memory phase per wave).
-    float mean_r[kCullPerThread][3], smax_r[kCullPerThread], opac_r[kCullPerThread];
+    float mean_r[kCullPerThread][3], smax_r[kCullPerThread];
     const uint32_t last = vp.total_splats ? vp.total_splats - 1 : 0;
 #pragma unroll
     for (uint32_t r = 0; r < kCullPerThread; r++) {
@@ -327,16 +343,13 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
 #pragma unroll
             for (int k = 0; k < 3; k++) mean_r[r][k] = means[g * 3 + k];
             smax_r[r] = fmaxf(log_scales[g * 3], fmaxf(log_scales[g * 3 + 1], log_scales[g * 3 + 2]));
-            opac_r[r] = raw_opac[g];
         } else {
             mean_r[r][0] = mean_r[r][1] = mean_r[r][2] = 0.0f;
             smax_r[r] = 0.0f;
-            opac_r[r] = 0.0f;
         }
     }
     uint32_t n_cand = 0;
     uint32_t *list = vis_list[threadIdx.x / kWave];
-    float *list_opac = vis_opac[threadIdx.x / kWave];
 #pragma unroll
     for (uint32_t r = 0; r < kCullPerThread; r++) {
         const uint32_t g = blockIdx.x * kCullBlock + r * kThreads + threadIdx.x;
@@ -363,11 +376,7 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
             compact_from_global[g] = kInvalid;
         }
         const uint64_t bal = __ballot(maybe);
-        if (maybe) {
-            const uint32_t slot = n_cand + __popcll(bal & lanemask_lt());
-            list[slot] = g;
-            list_opac[slot] = opac_r[r];
-        }
+        if (maybe) list[n_cand + __popcll(bal & lanemask_lt())] = g;
         n_cand += __popcll(bal);
     }
     __builtin_amdgcn_wave_barrier();
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                     det_expf(log_scales[(size_t)g * 3 + 2])};
             const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
             const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-            const float ro = list_opac[i];
+            const float ro = raw_opac[g];
             const float *sh = sh_coeffs + (size_t)g * ((DEG + 1) * (DEG + 1)) * 3;
             float p_view[3], cov2d[3];
             to_view(vp, mean, p_view);
@@ -541,9 +550,8 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
             conic[0] = r0.z, conic[1] = r0.w, conic[2] = r1.x;
             opac = r1.y;
             rgb[0] = r2.x, rgb[1] = r2.y, rgb[2] = r2.z;
-            const uint32_t radius = radius_from_conic(conic);
-            get_tile_bbox(xy, radius, vp.tile_bounds, bb);
             tt = make_tile_test(conic, opac);
+            walk_rect(xy, conic, tt, make_tile_reach(tt), vp.tile_bounds, bb);
         }
         // exact tile count (project_visible.wgsl:244-250): inline for small bboxes, queued otherwise.
         // Queue slots are reserved by a wave scan of the chunk counts ...
@@ -636,13 +644,14 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
         s.xy[0] = s.xy[1] = 0.f;
         s.tt.q[0] = s.tt.q[1] = s.tt.q[2] = 0.f;
         s.tt.any = false;
+        s.reach.rx = s.reach.ry = 0.f;
         s.b0 = s.b1 = s.area = 0u;
         s.bw = 1u;
         if (valid) s = load_walk(vp, projected, item.x);
         const uint32_t first = item.y * kChunkTiles;
         const uint32_t len = (valid && first < s.area) ? min(s.area - first, kChunkTiles) : 0u;
         uint64_t my_mask = 0;
-        const TileReach reach = make_tile_reach(s.tt);
+        const TileReach reach = s.reach;
         LateState st;
         late_reset(ring, st);
         const uint32_t in_group = min(G, n_items - grp * G);
@@ -657,7 +666,9 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
             const float xy[2] = {bcastf(s.xy[0], qi), bcastf(s.xy[1], qi)};
             const uint32_t b0 = bcast(s.b0, qi), b1 = bcast(s.b1, qi), bw = bcast(s.bw, qi);
             const uint32_t i = bcast(first, qi) + lane;
-            const uint32_t tx = b0 + i % bw, ty = b1 + i / bw;
+            uint32_t row, col;
+            row_col(i, bw, row, col);
+            const uint32_t tx = b0 + col, ty = b1 + row;
             const uint32_t cls = lane < qlen ? tile_test_head(t, r, tx, ty, xy) : kTileMiss;
             const uint64_t bal = __ballot(cls == kTileHit);
             if (lane == qi) my_mask = bal;
@@ -677,6 +688,29 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
 // ---- MapGaussiansToIntersect ---------------------------------------------------------------
 // map_gaussian_to_intersects.wgsl:10-48: splats walked inline by project_visible emit here inline;
 // queued splats are emitted by the queue role of the same launch.
+// Index of the k-th set bit (k = 0 is the lowest) of a 64-bit mask that has more than k bits set.
+__device__ __forceinline__ uint32_t kth_set_bit(uint64_t m, uint32_t k) {
+    uint32_t w = (uint32_t)m, base = 0;
+    const uint32_t c0 = __popc(w);
+    if (k >= c0) k -= c0, w = (uint32_t)(m >> 32), base = 32;
+#pragma unroll
+    for (uint32_t s = 16; s >= 1; s >>= 1) {
+        const uint32_t c = __popc(w & ((1u << s) - 1u));
+        if (k >= c) k -= c, w >>= s, base += s;
+    }
+    return base;
+}
+
+// Inline splats, two forms chosen from the visible count (block-uniform):
+//  * up to kFlatEmitMin visible splats: one lane per splat replays its recorded hit mask into its own output run (the
+//    launch is bound by its dependent-load chain, the short serial loops are free);
+//  * beyond: the wave's 64 consecutive inline splats own ONE contiguous output range (their offsets are consecutive
+//    values of the scan), so the emission is flattened like the count walk: lane l of step s writes entry 64 s + l of
+//    that range, finding its splat by a shuffle binary search over the running hit counts and its tile as the k-th set
+//    bit of that splat's hit mask.  Consecutive lanes, consecutive addresses: at 2 M visible splats / 18 M
+//    intersections 139 -> 79 us for the launch (lane-private runs: a stride of ~9 entries between neighbouring lanes);
+//    at 100 k visible splats the flat form is 2 us SLOWER (same-box A/B), hence the switch.
+constexpr uint32_t kFlatEmitMin = 1u << 19;
 __device__ __forceinline__ void map_inline_role(uint32_t bid, uint32_t nblocks, const ViewParams &vp,
                                                 const float *__restrict__ projected,
                                                 const uint32_t *__restrict__ cum_tiles_hit,
@@ -684,33 +718,69 @@ __device__ __forceinline__ void map_inline_role(uint32_t bid, uint32_t nblocks, 
                                                 uint32_t *__restrict__ tile_ids, uint32_t *__restrict__ gids,
                                                 const WalkQueue &q) {
     const uint32_t V = *num_visible;
-    for (uint32_t c = bid * kThreads + threadIdx.x; c < V; c += nblocks * kThreads) {
-        const uint32_t code = q.slot_of[c];
-        if (!(code & kInlineFlag)) continue;  // queued: emitted by the queue role
-        const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
-        const float xy[2] = {p[0], p[1]};
-        const float conic[3] = {p[2], p[3], p[4]};
-        const uint32_t radius = radius_from_conic(conic);
-        uint32_t bb[4];
-        get_tile_bbox(xy, radius, vp.tile_bounds, bb);
-        uint32_t isect = c > 0 ? cum_tiles_hit[c - 1] : 0u;
-        if (code == kInlineRetest) {
-            const TileTest tt = make_tile_test(conic, p[8]);
-            walk_inline_emit(bb, tt, xy, c, isect, vp.tile_bounds[0], cap, tile_ids, gids);
-        } else {
-            // replay the hit mask recorded by project_visible (row-major over the bbox)
-            const uint32_t bw = bb[2] - bb[0];
-            uint64_t mask = q.inline_mask[c];
-            while (mask) {
+    const uint32_t lane = lane_id();
+    const bool flat = V >= kFlatEmitMin;
+    const uint32_t wave_stride = nblocks * kThreads;
+    for (uint32_t cbase = bid * kThreads + (threadIdx.x / kWave) * kWave; cbase < V; cbase += wave_stride) {  // wave-uniform
+        const uint32_t c = cbase + lane;
+        const uint32_t code = c < V ? q.slot_of[c] : 0u;
+        const bool replay = (code & kInlineFlag) && code != kInlineRetest;
+        uint32_t bb[4] = {0, 0, 0, 0};
+        uint32_t start = 0;
+        uint64_t mask = 0;
+        float xy[2] = {0.f, 0.f};
+        TileTest tt;
+        tt.q[0] = tt.q[1] = tt.q[2] = 0.f;
+        tt.any = false;
+        if (code & kInlineFlag) {  // inline splat (replayed or re-tested): its rectangle and its first output slot
+            const float *p = projected + (size_t)c * BRUSH_PROJECTED_FLOATS;
+            xy[0] = p[0], xy[1] = p[1];
+            const float conic[3] = {p[2], p[3], p[4]};
+            tt = make_tile_test(conic, p[8]);
+            walk_rect(xy, conic, tt, make_tile_reach(tt), vp.tile_bounds, bb);
+            start = c > 0 ? cum_tiles_hit[c - 1] : 0u;
+            if (replay) mask = q.inline_mask[c];
+        }
+        const uint32_t bw = bb[2] - bb[0];
+        if (!flat) {
+            uint32_t isect = start;
+            while (mask) {  // row-major over the walk rectangle
                 const uint32_t i = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 if (isect < cap) {
-                    tile_ids[isect] = (bb[0] + i % bw) + (bb[1] + i / bw) * vp.tile_bounds[0];
+                    uint32_t row, col;
+                    row_col(i, bw, row, col);
+                    tile_ids[isect] = (bb[0] + col) + (bb[1] + row) * vp.tile_bounds[0];
                     gids[isect] = c;
                     isect++;
                 }
             }
+        } else {
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            const uint32_t incl = wave_inclusive_scan(cnt), excl = incl - cnt;
+            const uint32_t total = __shfl(incl, 63, 64);
+            const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+            for (uint32_t base = 0; base < total; base += kWave) {  // wave-uniform
+                const uint32_t j = base + lane;
+                uint32_t own = 0;
+#pragma unroll
+                for (uint32_t step = 32; step > 0; step >>= 1)
+                    if (__shfl(incl, own + step - 1, 64) <= j) own += step;
+                own = min(own, kWave - 1);
+                const uint64_t omask = ((uint64_t)__shfl(mhi, own, 64) << 32) | __shfl(mlo, own, 64);
+                const uint32_t ob0 = __shfl(bb[0], own, 64), ob1 = __shfl(bb[1], own, 64), obw = __shfl(bw, own, 64);
+                const uint32_t k = j - __shfl(excl, own, 64);
+                const uint32_t pos = __shfl(start, own, 64) + k;
+                if (j < total && pos < cap) {
+                    uint32_t row, col;
+                    row_col(kth_set_bit(omask, k), obw, row, col);
+                    tile_ids[pos] = (ob0 + col) + (ob1 + row) * vp.tile_bounds[0];
+                    gids[pos] = cbase + own;
+                }
+            }
         }
+        // queue-full fallback: the splat was counted by an inline walk and is walked again here (rare)
+        if (code == kInlineRetest) walk_inline_emit(bb, tt, xy, c, start, vp.tile_bounds[0], cap, tile_ids, gids);
     }
 }
 
@@ -759,7 +829,8 @@ __device__ __forceinline__ void map_queue_role(uint32_t bid, uint32_t nblocks, c
             const float xy[2] = {pp[0], pp[1]};
             const float conic[3] = {pp[2], pp[3], pp[4]};
             uint32_t bb[4];
-            get_tile_bbox(xy, radius_from_conic(conic), vp.tile_bounds, bb);
+            const TileTest tt = make_tile_test(conic, pp[8]);
+            walk_rect(xy, conic, tt, make_tile_reach(tt), vp.tile_bounds, bb);
             b0 = bb[0], b1 = bb[1], bw = bb[2] - bb[0];
             first = k * kChunkTiles;
             base = (c > 0 ? cum_tiles_hit[c - 1] : 0u) + before;
@@ -774,7 +845,9 @@ __device__ __forceinline__ void map_queue_role(uint32_t bid, uint32_t nblocks, c
             const uint32_t pos = bcast(base, qi) + __popcll(bal & lt);
             const uint32_t qc = bcast(item.x, qi);
             if (((bal >> lane) & 1ull) && pos < cap) {
-                tile_ids[pos] = (qb0 + i % qbw) + (qb1 + i / qbw) * vp.tile_bounds[0];
+                uint32_t row, col;
+                row_col(i, qbw, row, col);
+                tile_ids[pos] = (qb0 + col) + (qb1 + row) * vp.tile_bounds[0];
                 gids[pos] = qc;
             }
         }

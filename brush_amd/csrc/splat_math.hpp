@@ -319,6 +319,35 @@ __device__ __forceinline__ TileReach make_tile_reach(const TileTest &t) {
     r.ry = ok ? hy * 1.001f + (half + 0.02f) : __builtin_inff();
     return r;
 }
+// The rectangle of tiles a walk has to visit: the reference's bbox (get_tile_bbox: radius 3 sigma of the LARGER axis,
+// opacity-blind) cut down to the tiles the opacity-aware ellipse of the exact test can reach at all
+// (the kTileMiss exit above, applied to whole rows and columns at once; one tile of slack on either side for the
+// rounding of the bounds).  Tiles outside it are misses of can_be_visible(), so the hits and their row-major ORDER are
+// unchanged; what changes is how many candidates are enumerated (measured over the bench scenes: 23-32 % fewer) and how
+// many 64-tile chunks a large splat is cut into.  Every kernel that walks or replays a splat's tiles derives the
+// rectangle with this one function from the same ProjectedSplat bits, so they all agree on it.
+__device__ __forceinline__ void walk_rect(const float xy[2], const float conic[3], const TileTest &t,
+                                          const TileReach &r, const uint32_t bounds[2], uint32_t bb[4]) {
+    get_tile_bbox(xy, radius_from_conic(conic), bounds, bb);
+    if (!t.any) {  // log(255 opac) <= 0: no tile can be visible (helpers.wgsl:264-279)
+        bb[2] = bb[0], bb[3] = bb[1];
+        return;
+    }
+    const float rr[2] = {r.rx, r.ry};
+    const float half = (float)kTileWidth / 2.0f;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (!(rr[i] < 3.0e37f)) continue;  // reach unknown: the whole bbox
+        // tile t can be reached only if |xy - (16 t + 8)| <= r  <=>  t in [(xy - r - 8) / 16, (xy + r - 8) / 16]
+        const int32_t lo = f2i_sat(floorf((xy[i] - rr[i] - half) / (float)kTileWidth)) - 1;
+        const int32_t hi = f2i_sat(floorf((xy[i] + rr[i] - half) / (float)kTileWidth)) + 2;  // exclusive
+        const uint32_t nlo = (uint32_t)iclamp(lo, (int32_t)bb[i], (int32_t)bb[2 + i]);
+        const uint32_t nhi = (uint32_t)iclamp(hi, (int32_t)bb[i], (int32_t)bb[2 + i]);
+        bb[i] = nlo;
+        bb[2 + i] = nhi > nlo ? nhi : nlo;
+    }
+}
+
 __device__ __forceinline__ uint32_t tile_test_head(const TileTest &t, const TileReach &r, uint32_t tx, uint32_t ty,
                                                    const float center[2]) {
     if (!t.any) return kTileMiss;

@@ -48,6 +48,16 @@ int main(int argc, char **argv) {
             else if (fabsf(dd[0]) > rx || fabsf(dd[1]) > ry) cls = 0;
             else cls = 2;
         }
+        /* walk_rect (splat_math.hpp): a tile the exact test accepts must lie inside the rectangle the walks enumerate */
+        if (exact && ok) {
+            float cxy[2] = {xy[0], xy[1]}, rr[2] = {rx, ry};
+            uint32_t tt[2] = {tx, ty};
+            for (int k = 0; k < 2; k++) {
+                long lo = (long)floorf((cxy[k] - rr[k] - 8.0f) / 16.0f) - 1;
+                long hi = (long)floorf((cxy[k] + rr[k] - 8.0f) / 16.0f) + 2;
+                if ((long)tt[k] < lo || (long)tt[k] >= hi) bad++;
+            }
+        }
         if (cls == 0) { miss_exit++; if (exact) bad++; }
         if (cls == 1) { hit_exit++; if (!exact) bad++; }
         if (cls == 2) edge++;
