@@ -93,6 +93,9 @@ size_t sort_workspace_bytes(uint32_t max_n);
 // vals_in == nullptr sorts the positions 0..n-1 themselves (argsort proper).
 // edges != nullptr (zero-initialised [edge_keys][2], keys < edge_keys): the last pass also records the run of every
 // key value k in the sorted output as edges[2k] = ~start, edges[2k+1] = end (both 0 for a key that does not occur).
+// keys_out == nullptr (internal callers only, bits > 0): the sorted keys themselves are not written (4 B per pair less
+// in the last pass); with an even number of passes the ping-pong puts the LAST pass's keys there, which is the only
+// output dropped.
 hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
                        uint32_t *vals_out, const uint32_t *d_n, uint32_t max_n, uint32_t bits,
                        void *ws, hipStream_t s, uint32_t *edges = nullptr, uint32_t edge_keys = 0);

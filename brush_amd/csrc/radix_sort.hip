@@ -273,7 +273,7 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
             if (idx < n) {
                 const uint32_t digit = (key[i] >> shift) & mask;
                 const uint32_t pos = L.digit_base[digit] + L.wave_hist[wid][digit] + rank[i];
-                keys_out[pos] = key[i];
+                if (keys_out) keys_out[pos] = key[i];
                 vals_out[pos] = val[i];
             }
         }
@@ -303,7 +303,7 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
             const uint32_t digit = (k >> shift) & mask;
             const uint32_t ts = L.tile_start[digit];
             const uint32_t pos = L.digit_base[digit] + (lp - ts);
-            keys_out[pos] = k;
+            if (keys_out) keys_out[pos] = k;  // nullptr: nobody reads the sorted keys (the run edges are found right here)
             vals_out[pos] = L.vals[lp];
             // LAST pass only (edges != nullptr): the keys are in their final order, so the run of equal keys around
             // `pos` is a bin of the caller (GetTileBinEdges, get_tile_bin_edges.wgsl:15-42, without its launch).  A key
@@ -411,6 +411,7 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
                        hipStream_t s, uint32_t *edges, uint32_t edge_keys) {
     if (max_n == 0) return hipSuccess;
     if (edges && bits == 0) return hipErrorInvalidValue;  // the edges come out of the last pass
+    if (!keys_out && (bits == 0 || bits > 16)) return hipErrorInvalidValue;  // only the LAST of <= 2 passes may drop its keys
     const SortWs w = carve_sort(ws, max_n);
     const uint32_t total_bits = 4u * ((bits + 3u) / 4u);  // brush-sort/src/lib.rs:58
     const uint32_t passes = (total_bits + 7u) / 8u;
@@ -428,7 +429,7 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
         const uint32_t width = min(8u, total_bits - shift);
         const uint32_t mask = (1u << width) - 1u;
         const bool to_out = ((passes - 1 - p) % 2u) == 0;
-        uint32_t *dst_k = to_out ? keys_out : w.tmp_keys;
+        uint32_t *dst_k = to_out ? keys_out : w.tmp_keys;  // keys_out may be nullptr: the last pass then writes no keys
         uint32_t *dst_v = to_out ? vals_out : w.tmp_vals;
         uint32_t *pass_edges = p + 1 == passes ? edges : nullptr;
         if (fused) {

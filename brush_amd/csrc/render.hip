@@ -245,7 +245,11 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
     // the sort's last pass sees every key next to its neighbours in final order and records the edges of the runs
     // (ws.bin_edges), the compositing kernel decodes them and writes aux.tile_bins.
     const bool det = aux_det(aux);
-    BRUSH_HIP_CHECK(sort_launch(ws.tile_unsorted, det ? nullptr : ws.gid_unsorted, ws.tile_sorted,
+    // The sorted tile ids are read by nobody once the edges come out of the sort: not written in the default mode.  (With
+    // three or more passes, i.e. more than 65 535 tiles, the ping-pong also routes an intermediate pass through the
+    // output buffer, so it is kept then.)
+    const bool drop_keys = !det && bits <= 16;
+    BRUSH_HIP_CHECK(sort_launch(ws.tile_unsorted, det ? nullptr : ws.gid_unsorted, drop_keys ? nullptr : ws.tile_sorted,
                                 det ? aux.isect_unsorted_pos : aux.compact_gid_from_isect, aux.num_intersections, cap,
                                 bits, ws.sort_ws, s, det ? nullptr : ws.bin_edges, num_tiles));
     mark_fwd(s, 1 + BRUSH_STAGE_TILE_SORT);

@@ -80,6 +80,18 @@ STAGES = {"project_cull": ["k_project_cull", "k_cull_scan", "k_compact"], "proje
           "sort": ["k_sort_upsweep", "k_sort_scan", "k_sort_downsweep"]}
 traffic["valu_insts"] = {}
 traffic["_tag"] = tag
+try:  # the bench line quotes this: which commit the counters were taken at
+    import subprocess
+    traffic["_commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    pass
+if os.path.exists("profiles/traffic.json"):  # keep the heavy workloads' section (tools/summarize_extra.py)
+    try:
+        old = json.load(open("profiles/traffic.json"))
+        if "extra" in old:
+            traffic["extra"] = old["extra"]
+    except ValueError:
+        pass
 for stage, ks in STAGES.items():
     b = [traffic["kernels"][k]["hbm_bytes_per_launch"] for k in ks if k in traffic["kernels"]]
     if b:
