@@ -15,6 +15,8 @@ __global__ __launch_bounds__(256) void k(float *out, float seed) {
 #pragma unroll
     for (int i = 0; i < 16; i++) { r[i] = seed + i + threadIdx.x; q[i] = make_float2(r[i], r[i] + 1.f); }
     float a = seed * 0.5f, b = seed * 0.25f;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int it = 0; it < kIters; it++) {
 #define FMA(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b));
 #define PKFMA(i) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(q[i]) : "v"(q[(i + 1) & 15]));
@@ -40,7 +42,15 @@ __global__ __launch_bounds__(256) void k(float *out, float seed) {
         if (KIND == 9) { REP16(CNDS) }
         if (KIND == 10) { REP16(MUL) }
         if (KIND == 11) { REP16(DPP) }
+        // mixes (issue-port sharing between the VALU and the matrix pipe): 96 fma, then nothing / 9 MFMA / 32 DPP adds
+        if (KIND >= 12 && KIND <= 14) { REP16(FMA) REP16(FMA) REP16(FMA) REP16(FMA) REP16(FMA) REP16(FMA) }
+        if (KIND == 13 || KIND == 15) {
+#define MF(i) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[(i) % 3]) : "v"(r[i]), "v"(b));
+            MF(0) MF(1) MF(2) MF(3) MF(4) MF(5) MF(6) MF(7) MF(8)
+        }
+        if (KIND == 14) { REP16(DPP) REP16(DPP) }
     }
+    if (KIND == 13 || KIND == 15) r[0] += acc[0].x + acc[1].y + acc[2].z;
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) s += r[i] + q[i].x + q[i].y;
@@ -48,8 +58,8 @@ __global__ __launch_bounds__(256) void k(float *out, float seed) {
 }
 
 template <int KIND>
-double run(const char *name, float *d, double ghz) {
-    const int blocks = 256 * 8;  // 8 workgroups of 4 waves per CU -> 8 waves per SIMD
+double run(const char *name, float *d, double ghz, int wg_per_cu = 8) {
+    const int blocks = 256 * wg_per_cu;  // wg_per_cu workgroups of 4 waves per CU -> as many waves per SIMD
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, 1.0f);
@@ -59,7 +69,7 @@ double run(const char *name, float *d, double ghz) {
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double instr_per_simd = 8.0 * kIters * 16;  // 8 waves on each SIMD
+    const double instr_per_simd = (double)wg_per_cu * kIters * 16;
     const double cyc = ms * 1e-3 * ghz * 1e9 / instr_per_simd;
     printf("%-14s %8.3f ms  %6.2f SIMD-cycles per wave64 instruction (at %.2f GHz)\n", name, ms, cyc, ghz);
     return cyc;
@@ -74,5 +84,9 @@ int main() {
     run<3>("v_exp_f32", d, ghz); run<4>("v_rcp_f32", d, ghz); run<5>("v_min_f32", d, ghz);
     run<6>("v_cmp (vcc)", d, ghz); run<7>("v_cmp (sgpr)", d, ghz); run<8>("v_cndmask vcc", d, ghz);
     run<9>("v_cndmask sgpr", d, ghz); run<11>("v_add_f32 dpp", d, ghz);
+    // per iteration of 16 "slots": cycles x 16 = SIMD cycles per iteration and wave
+    printf("mixes at 4 waves per SIMD; SIMD cycles per iteration and wave = printed value x 16\n");
+    run<12>("96 fma", d, ghz, 4); run<13>("96 fma + 9 mfma16x16x4", d, ghz, 4); run<14>("96 fma + 32 dpp add", d, ghz, 4);
+    run<15>("9 mfma16x16x4", d, ghz, 4);
     return 0;
 }
