@@ -260,6 +260,23 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     return v;
 }
 
+// Staged records of the backward, one array per field (the forward's QuadRec pads the opacity to 16 bytes).
+struct BwdRecs {
+    float4 a[kBatch];    // mean.x, mean.y, conic.x, conic.y
+    float4 b[kBatch];    // conic.z, r, g, b
+    float opac[kBatch];
+};
+// Default-mode reduction of the per-record lane partials.  Cross-lane VALU adds (DPP, lane swaps) cost 6 SIMD cycles
+// each beside this kernel's arithmetic and a plain v_add_f32 2.7 (tools/ubench/valu_rate.hip), so the 64:1 sums are
+// TRANSPOSED through LDS instead: the wave stores the 9 partials of every lane as 9 rows of 64 words (plain LDS stores,
+// not VALU work), and once kStageRecs records wait, 2 lanes per row read half a row each (8 ds_read_b128) and add it up
+// with plain adds: 31 adds + one lane swap per kStageRecs records instead of 26 cross-lane adds per record.  Rows start
+// kRowWords apart so that the 8 lanes the LDS serves per cycle read 8 different groups of 4 banks.
+constexpr uint32_t kStageRecs = 3;
+constexpr uint32_t kRowWords = 68;
+constexpr uint32_t kStageRows = kStageRecs * kGradComps;
+static_assert(kStageRows <= 32, "one row per lane pair");
+
 // Footprint-aware backward.  A wave owns NQ quadrants of one tile (NQ = 4: one wave per tile, NQ = 2:
 // upper / lower half, NQ = 1: one quadrant), one pixel per lane PER QUADRANT, so a lane's gradient
 // contributions of all its quadrants are summed in registers and the 9-component wave reduction runs
@@ -282,16 +299,18 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
     float *__restrict__ rows) {
     static_assert(!DET || NQ == 4, "deterministic mode: one wave per tile");
     __shared__ uint32_t lds_pos_all[DET ? TPB : 1][kBatch];
-    __shared__ QuadRec lds_all[TPB][kBatch];
+    __shared__ BwdRecs lds_all[TPB];
     __shared__ uint32_t lds_gid_all[TPB][kBatch];
-    __shared__ float acc_all[TPB][kBatch][12];  // 9 used; 48-byte rows keep b128 stores aligned
+    __shared__ float acc_all[DET ? TPB : 1][kBatch][12];  // DET: 9 used; 48-byte rows keep b128 stores aligned
+    __shared__ float stage_all[DET ? 1 : TPB][kStageRows * kRowWords];
     constexpr uint32_t kWavesPerTile = 4u / NQ;
 
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    QuadRec *lds = lds_all[wv];
+    BwdRecs &lds = lds_all[wv];
     uint32_t *lds_gid = lds_gid_all[wv];
     uint32_t *lds_pos = lds_pos_all[DET ? wv : 0];
-    float(*acc)[12] = acc_all[wv];
+    float(*acc)[12] = acc_all[DET ? wv : 0];
+    float *stage = stage_all[DET ? 0 : wv];
     const uint32_t unit = ((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * TPB + wv;  // XCD-contiguous
     const uint32_t tile_id = unit / kWavesPerTile, sub = unit % kWavesPerTile;
     if (tile_id >= num_tiles) return;
@@ -377,16 +396,49 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
         }
         if ((todo >> lane) & 1ull) {
             lds_gid[lane] = cg_id;
-            lds[lane].a = make_float4(rec[0], rec[1], rec[2], rec[3]);
-            lds[lane].b = make_float4(rec[4], rec[5], rec[6], rec[7]);
-            lds[lane].c = make_float4(rec[8], 0.f, 0.f, 0.f);
+            lds.a[lane] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+            lds.b[lane] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+            lds.opac[lane] = rec[8];
         }
-        {
+        if (DET) {
             float4 *row = reinterpret_cast<float4 *>(&acc[lane][0]);
             row[0] = row[1] = row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         wave_sync();
         const uint64_t flush_mask = todo;
+        // Default mode: records whose partial sums wait in `stage` (slot s holds batch slot (staged_t >> 6 s) & 63)
+        uint32_t staged = 0u;
+        uint64_t staged_t = 0ull;
+        // The transposed reduction of the staged records (see kStageRecs): lane (row, half) = (l & 31, l >> 5) adds half
+        // of row `row` = (stage slot, component), the halves meet through one lane swap, and the lower lane applies the
+        // per-record factor and issues the hardware float atomic: 9 consecutive lanes on the 9 consecutive words of one
+        // splat's compact row, as the L2 executes float atomics line by line.
+        auto reduce_stage = [&](const uint32_t cnt) {
+            const uint32_t row = lane & 31u, half = lane >> 5;
+            float sum = 0.0f;
+            if (row < cnt * kGradComps) {
+                const float4 *src = reinterpret_cast<const float4 *>(stage + row * kRowWords + half * 32u);
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = src[k];
+                float p[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) p[k] = (v[k].x + v[k].y) + (v[k].z + v[k].w);
+                sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+            }
+            sum = fold_swap32(sum, sum);  // every lane: lower + upper half of its row
+            if (lane < cnt * kGradComps) {
+                const uint32_t slot = (row * 57u) >> 9;  // row / 9 for row < 32
+                const uint32_t k = row - slot * kGradComps;
+                const uint32_t t = (uint32_t)(staged_t >> (6u * slot)) & 63u;
+                // rasterize_backwards.wgsl:256-263: v_xy = -opac (sum vva gx, sum vva gy), v_conic = -opac (S2 / 2, S3,
+                // S4 / 2), v_rgb, v_opac = S8
+                const float nopac = -lds.opac[t];
+                const float scale = k >= 5u ? 1.0f : ((k == 2u || k == 4u) ? 0.5f * nopac : nopac);
+                const float val = sum * scale;
+                if (val != 0.0f) unsafeAtomicAdd(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], val);
+            }
+        };
         // One record: its LDS row is read one record AHEAD (software pipeline, two register sets in turn), so the
         // broadcast's latency is covered by the previous record's arithmetic instead of stalling the wave.
         auto one_record = [&](const uint32_t t, const float4 a, const float4 b, const float opac) {
@@ -431,15 +483,21 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
                     KD[s] = fmaf(-fac, cv, KD[s]);
                     // v_sigma = -opac vis v_alpha; the factors that are the same for every pixel (-opac, the conic
                     // in gx / gy, the 1/2 of the conic terms) are applied once per record at the flush:
-                    //   g0 = sum vva dx, g1 = sum vva dy, g2..4 = sum vva (dx dx, dx dy, dy dy), g8 = sum vva
+                    //   g0 = sum vva dx, g1 = sum vva dy (default mode: vva gx, vva gy), g2..4 = sum vva (dx dx, dx dy,
+                    //   dy dy), g8 = sum vva
 #ifdef BRUSH_INJECT_VVA_ULPS  // test-only build (libbrush_hip_inject.so): a one-signed error of that many eps32 per term
                     const float vva = fmaf(fabsf(vis * v_alpha), BRUSH_INJECT_VVA_ULPS * 5.9604645e-8f, vis * v_alpha);
 #else
                     const float vva = vis * v_alpha;
 #endif
                     const float wx = vva * dx, wy = vva * dy;
-                    g[0] += wx;
-                    g[1] += wy;
+                    if (DET) {
+                        g[0] += wx;
+                        g[1] += wy;
+                    } else {  // the conic factors of v_xy applied per pixel: the flush scales single sums only
+                        g[0] = fmaf(vva, gx, g[0]);
+                        g[1] = fmaf(vva, gy, g[1]);
+                    }
                     g[2] = fmaf(wx, dx, g[2]);
                     g[3] = fmaf(wx, dy, g[3]);
                     g[4] = fmaf(wy, dy, g[4]);
@@ -451,6 +509,18 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
                 }
             }
             if (ballot64(contributed) != 0ull) {  // wave-uniform: all 64 lanes take part in the reduction
+                if constexpr (!DET) {
+                    // park the lane partials as 9 rows of the stage: plain LDS stores, no cross-lane VALU work
+                    float *dst = stage + staged * (kGradComps * kRowWords) + lane;
+#pragma unroll
+                    for (uint32_t k = 0; k < kGradComps; k++) dst[k * kRowWords] = g[k];
+                    staged_t |= (uint64_t)t << (6u * staged);
+                    if (++staged == kStageRecs) {
+                        reduce_stage(kStageRecs);
+                        staged = 0u, staged_t = 0ull;
+                    }
+                    return;
+                }
                 const float u0 = fold_swap32(g[0], g[1]), u1 = fold_swap32(g[2], g[3]);
                 const float u2 = fold_swap32(g[4], g[5]), u3 = fold_swap32(g[6], g[7]);
                 const float w0 = row_sum_lane15(fold_swap16(u0, u1));
@@ -467,34 +537,38 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
         };
         {
             uint32_t tA = (uint32_t)__builtin_ctzll(todo), tB = tA;
-            float4 aA = lds[tA].a, bA = lds[tA].b, aB, bB;
-            float oA = lds[tA].c.x, oB;
+            float4 aA = lds.a[tA], bA = lds.b[tA], aB, bB;
+            float oA = lds.opac[tA], oB;
             for (;;) {
                 todo &= todo - 1ull;
                 tB = todo != 0ull ? (uint32_t)__builtin_ctzll(todo) : tA;
-                aB = lds[tB].a, bB = lds[tB].b, oB = lds[tB].c.x;
+                aB = lds.a[tB], bB = lds.b[tB], oB = lds.opac[tB];
                 one_record(tA, aA, bA, oA);
                 if (todo == 0ull) break;
                 todo &= todo - 1ull;
                 tA = todo != 0ull ? (uint32_t)__builtin_ctzll(todo) : tB;
-                aA = lds[tA].a, bA = lds[tA].b, oA = lds[tA].c.x;
+                aA = lds.a[tA], bA = lds.b[tA], oA = lds.opac[tA];
                 one_record(tB, aB, bB, oB);
                 if (todo == 0ull) break;
             }
         }
+        if constexpr (!DET) {
+            if (staged != 0u) reduce_stage(staged);
+            batch_end -= remaining;
+            continue;
+        }
         wave_sync();
-        // Flush the staged records: one hardware float atomic per (wave, splat, component); consecutive
-        // lanes take consecutive components of one splat.
+        // DET: flush the batch's rows.
         // acc holds the raw pixel sums; the per-record factors (rasterize_backwards.wgsl:256-263):
         //   v_xy = -opac (a S0 + b S1, b S0 + c S1), v_conic = -opac (S2 / 2, S3, S4 / 2), v_rgb, v_opac = S8
         auto finish = [&](uint32_t t, uint32_t k) -> float {
             const float v = acc[t][k];
             if (k >= 5u) return v;
-            const float4 a = lds[t].a;
-            const float nopac = -lds[t].c.x;
+            const float4 a = lds.a[t];
+            const float nopac = -lds.opac[t];
             if (k >= 2u) return (k == 3u ? nopac : 0.5f * nopac) * v;
             const float other = acc[t][k ^ 1u];
-            return nopac * (k == 0u ? fmaf(a.z, v, a.w * other) : fmaf(lds[t].b.x, v, a.w * other));
+            return nopac * (k == 0u ? fmaf(a.z, v, a.w * other) : fmaf(lds.b[t].x, v, a.w * other));
         };
         if (DET) {
             // one row per intersection of the batch (zeros where nothing contributed), 12 consecutive lanes per row
@@ -557,7 +631,7 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
     // tile and the tiles' lists are about equally long, so the launch proceeds in rounds of (SIMDs x k) waves and a
     // partly filled last round costs as much as a full one: k in {3, 4, 5} is chosen to waste the least of the last
     // round (1080p: 8160 waves on 1024 SIMDs, k = 4 -> 2 rounds, 152 us; k = 5 -> 1.6 rounds, 164 us; k = 3: 177 us).
-    // The registers allow up to 5; fewer are enforced with unused dynamic LDS per workgroup.  Workgroups of 4 waves
+    // Registers and static LDS allow 4; fewer are enforced with unused dynamic LDS per workgroup.  Workgroups of 4 waves
     // (4 tiles in a row): 1, 2 and 8 measured slower (154 / 157 / 172 vs 142 us).
     static std::atomic<uint32_t> simds_of[kMaxDevices];  // per device (0 = not queried yet)
     const int slot = current_device_slot();
@@ -570,29 +644,37 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
         simds = (uint32_t)cus * 4u;
         simds_of[slot].store(simds, std::memory_order_relaxed);
     }
-    auto lds_pad_for = [&](uint32_t units, uint32_t max_k) -> uint32_t {
+    // Dynamic LDS per workgroup that admits exactly k workgroups (of 4 waves) per CU beside `static_lds` bytes of static LDS.
+    constexpr uint32_t kLdsPerCu = 160u * 1024u;
+    auto lds_pad_for = [&](uint32_t units, uint32_t static_lds, uint32_t max_k_regs) -> uint32_t {
+        const uint32_t max_k = min(max_k_regs, kLdsPerCu / static_lds);
         uint32_t best_k = max_k, best_cost = 0xFFFFFFFFu;
         for (uint32_t k = max_k; k >= 3u; k--) {
             const uint32_t cost = ceil_div(units, simds * k) * k;  // in wave-rounds per SIMD
             if (cost < best_cost) best_cost = cost, best_k = k;
         }
-        // static LDS is ~6.3 KB per wave: 160 KB / (k waves x 4 SIMDs) per wave admits exactly k workgroups of 4 waves
-        return best_k >= 5u ? 0u : (best_k == 4u ? 2048u : 4096u);
+        if (best_k >= max_k_regs) return 0u;                    // the registers stop the (k+1)-th workgroup
+        const uint32_t per_wg = (kLdsPerCu / best_k) & ~1023u;  // (k + 1) of these do not fit
+        return per_wg > static_lds ? per_wg - static_lds : 0u;
     };
 #define BRUSH_RASTER_BWD(NQ, DET, UNSORTED, ROWS)                                                                     \
     hipLaunchKernelGGL((k_rasterize_backward_quad<NQ, DET, kTilesPerBlock>),                                          \
-                       dim3(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), dim3(kRasterThreads),                \
-                       lds_pad * kTilesPerBlock, s, w, h, tbx, tiles, compact_gid_from_isect, tile_bins, projected,   \
-                       final_index, out_img, v_out, v_compact, UNSORTED, ROWS)
+                       dim3(ceil_div(ceil_div(units, kTilesPerBlock), 8u) * 8u), dim3(kRasterThreads), lds_pad, s, w, \
+                       h, tbx, tiles, compact_gid_from_isect, tile_bins, projected, final_index, out_img, v_out,      \
+                       v_compact, UNSORTED, ROWS)
+    // static LDS per workgroup as the compiler lays it out (unused arrays of the other mode are dropped); registers:
+    // 110-122 VGPRs -> 4 waves per SIMD
+    constexpr uint32_t kStaticLdsDet = kTilesPerBlock * (sizeof(BwdRecs) + kBatch * (4u + 4u + 48u));
+    constexpr uint32_t kStaticLdsDefault = kTilesPerBlock * (sizeof(BwdRecs) + kBatch * 4u + kStageRows * kRowWords * 4u);
     if (rows) {  // deterministic mode: one wave per tile, one stored row per intersection
         const uint32_t units = tiles;
-        const uint32_t lds_pad = lds_pad_for(units, 4u);
+        const uint32_t lds_pad = lds_pad_for(units, kStaticLdsDet, 4u);
         BRUSH_RASTER_BWD(4, true, unsorted_pos, rows);
         return hipGetLastError();
     }
     const uint32_t nq = backward_quadrants_per_wave(tiles);
     const uint32_t units = tiles * (4u / nq);
-    const uint32_t lds_pad = lds_pad_for(units, 5u);
+    const uint32_t lds_pad = lds_pad_for(units, kStaticLdsDefault, 4u);
     if (nq == 4) BRUSH_RASTER_BWD(4, false, nullptr, nullptr);
     else if (nq == 2) BRUSH_RASTER_BWD(2, false, nullptr, nullptr);
     else BRUSH_RASTER_BWD(1, false, nullptr, nullptr);
