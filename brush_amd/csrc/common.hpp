@@ -48,7 +48,7 @@ static inline int current_device_slot() {
     return dev < kMaxDevices ? dev : kMaxDevices - 1;
 }
 
-static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Bump allocator over the caller's workspace (256-B aligned carve-outs).
