@@ -17,10 +17,13 @@
 //
 // Backward: replaces the reference's LDS gradient queue + nine software CAS loops per queued gradient
 // (rasterize_backwards.wgsl:47-135,276-301).  One wave per tile, one pixel per lane PER QUADRANT: a lane sums the 9
-// gradient components over its quadrants in registers, then ONE transposing wave64 reduction (v_permlane32/16_swap +
-// DPP row sums, 26 VALU) parks the tile totals in an LDS row.  When a batch retires the [64][9] block is flushed with
-// hardware global_atomic_add_f32, consecutive lanes on consecutive components of one splat's 64-byte compact row: the L2
-// executes float atomics line by line.  Records that touch no pixel of the tile skip reduction and flush.
+// gradient components over its quadrants in registers; the 64:1 sums are TRANSPOSED THROUGH LDS (the wave stores its
+// partials as rows of 64 words, two lanes per row add half a row each with plain v_add_f32, three records per pass: see
+// kStageRecs) because a cross-lane VALU add costs 6 SIMD cycles beside this kernel's arithmetic and a plain one 2.7.  The
+// reducing lanes apply the per-record factors and flush with hardware global_atomic_add_f32, consecutive lanes on
+// consecutive components of one splat's 64-byte compact row: the L2 executes float atomics line by line.  Records that
+// touch no pixel of the tile skip reduction and flush.  (Deterministic mode keeps the round-2 form: one transposing
+// wave64 reduction per record with v_permlane32/16_swap + DPP row sums, rows stored per intersection.)
 //
 // Roofline: both kernels are bound by fp32 VALU issue (and the backward by the L2's atomic rate), not by HBM;
 // DESIGN.md states the ceilings and the measurements.
