@@ -13,8 +13,10 @@
 //       (m/(1-b1^t) / (sqrt(v/(1-b2^t)) + eps)), eps = 1e-15 (train.rs:184).  The single-view trainer uses
 //       the fused form instead (project_bwd.hip, brush_render_backward_adam).
 //   k_normalize_quats, k_refine_stats : gaussian_splats.rs:174-175, train.rs:284-316.
-// Roofline: the blur kernels are VALU-issue bound (~200 instructions per pixel-channel-row), Adam is an
-// HBM stream (28 B/parameter).
+// Roofline: the blur kernels are VALU-issue bound (~200 / ~105 instructions per marched pixel-channel-row forward /
+// backward, of which 143 / 62 are the taps themselves; the file is built without the SLP vectorizer, whose v_pk_* pairs
+// cost more register moves than they save, and addresses are a wave-uniform row pointer plus a per-lane constant), Adam
+// is an HBM stream (28 B/parameter).
 #include "internal.hpp"
 
 namespace brush {
@@ -54,6 +56,15 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     return r;
 }
 
+// Element at a wave-uniform base plus a per-lane BYTE offset below 4 GiB: global_load/store with an SGPR base and a
+// 32-bit VGPR offset, no 64-bit vector address arithmetic.
+__device__ __forceinline__ float ld_off(const float *base, uint32_t byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void st_off(float *base, uint32_t byte_off, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
 // LDS traffic inside one wave is in order; this only stops the compiler from moving accesses.
 // A fence would also wait for the prefetched global loads, so this is a pure compiler barrier.
 __device__ __forceinline__ void wave_lds_sync() {
@@ -88,43 +99,60 @@ __global__ __launch_bounds__(192) void k_ssim_forward(const float *__restrict__ 
     const int ox = x0 + l;
     const bool out_col = l < G::kOutCols && ox < W2;
     const bool own_col = l >= G::kPad - 1 && l < G::kPad - 1 + G::kOutCols;
-    const size_t plane = (size_t)W2 * H2;
+    const uint32_t plane = (uint32_t)W2 * (uint32_t)H2;  // all element offsets fit 32 bits (checked by the host entry)
     float hq[WIN][5];
     float msum = 0.0f, l1 = 0.0f;
     // marched row r -> (a, b, alpha pair) of the lane's column, zero outside the image.  Loads are
     // unconditional (clamped address + select) and issued three rows ahead of their use, so the
     // vmcnt waits the compiler places leave the younger rows in flight.
+    // Addresses: the row is wave-uniform (scalar pointer arithmetic), the column offset a per-lane constant.
     const bool alpha_on = ch == 0 && gt_channels == 4;
-    const int ixc = min(max(ix, 0), (int)w - 1);
+    const uint32_t ixc = (uint32_t)min(max(ix, 0), (int)w - 1);
+    const uint32_t p_al = alpha_on ? 3u : (uint32_t)ch;
+    const uint32_t pc_a = (ixc * 4u + (uint32_t)ch) * 4u, pc_al = (ixc * 4u + p_al) * 4u;  // pred column byte offsets
+    const uint32_t gc_a = (ixc * gt_channels + (uint32_t)ch) * 4u, gc_al = (ixc * gt_channels + p_al) * 4u;  // gt
     struct Row {
         float a, b, pa, ga;
     };
     auto fetch = [&](int r) {
-        const int iy = oy0 - G::kPad + r;
-        const bool ok = col_ok && iy >= 0 && iy < (int)h;
-        const size_t px = (size_t)min(max(iy, 0), (int)h - 1) * w + ixc;
+        const int iy = oy0 - G::kPad + r;  // uniform
+        const bool row_ok = iy >= 0 && iy < (int)h;
+        const uint32_t iyc = (uint32_t)min(max(iy, 0), (int)h - 1);
+        const float *prow = pred + (size_t)iyc * w * 4u;
+        const float *grow = gt + (size_t)iyc * w * gt_channels;
+        const bool ok = col_ok && row_ok;
         Row v;
-        v.a = pred[px * 4 + ch];
-        v.b = gt[px * gt_channels + ch];
-        v.pa = pred[px * 4 + (alpha_on ? 3 : ch)];
-        v.ga = gt[px * gt_channels + (alpha_on ? 3 : ch)];
+        v.a = ld_off(prow, pc_a);
+        v.b = ld_off(grow, gc_a);
+        v.pa = v.ga = 0.0f;
+        if (alpha_on) {  // wave-uniform: the strided loads are what the kernel waits for (16 cache lines per instruction)
+            v.pa = ld_off(prow, pc_al);
+            v.ga = ld_off(grow, gc_al);
+            v.pa = ok ? v.pa : 0.0f, v.ga = ok ? v.ga : 0.0f;
+        }
         v.a = ok ? v.a : 0.0f, v.b = ok ? v.b : 0.0f;
-        v.pa = ok && alpha_on ? v.pa : 0.0f, v.ga = ok && alpha_on ? v.ga : 0.0f;
         return v;
     };
-    Row c0 = fetch(0), c1 = fetch(1), c2 = fetch(2);
+    // three rows in flight; slot j % 3 of the ring is static inside the WIN-fold unrolled body, and the ring is turned
+    // by WIN % 3 once per body instead of shifting it every row
+    Row pf[3] = {fetch(0), fetch(1), fetch(2)};
     for (int r0 = 0; r0 < G::kSegRows + WIN - 1; r0 += WIN) {
 #pragma unroll
         for (int j = 0; j < WIN; j++) {
             const int r = r0 + j;
-            ra[l] = c0.a, rb[l] = c0.b;
-            if (own_col && r >= G::kPad - 1 && r < G::kPad - 1 + G::kSegRows) l1 += fabsf(c0.a - c0.b) + fabsf(c0.pa - c0.ga);
-            c0 = c1, c1 = c2;
-            c2 = fetch(r + 3);
+            const Row c = pf[j % 3];
+            ra[l] = c.a, rb[l] = c.b;
+            if (own_col && r >= G::kPad - 1 && r < G::kPad - 1 + G::kSegRows) l1 += fabsf(c.a - c.b) + fabsf(c.pa - c.ga);
+            pf[j % 3] = fetch(r + 3);
             wave_lds_sync();
-            float sa = 0.f, sb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+            float sa, sb, saa, sbb, sab;
+            {
+                const float av = ra[l], bv = rb[l];
+                const float ga = win.g[0] * av, gb = win.g[0] * bv;
+                sa = ga, sb = gb, saa = ga * av, sbb = gb * bv, sab = ga * bv;
+            }
 #pragma unroll
-            for (int k = 0; k < WIN; k++) {
+            for (int k = 1; k < WIN; k++) {
                 const float av = ra[l + k], bv = rb[l + k];
                 const float ga = win.g[k] * av, gb = win.g[k] * bv;
                 sa += ga, sb += gb, saa += ga * av, sbb += gb * bv, sab += ga * bv;
@@ -133,9 +161,11 @@ __global__ __launch_bounds__(192) void k_ssim_forward(const float *__restrict__ 
             hq[j][0] = sa, hq[j][1] = sb, hq[j][2] = saa, hq[j][3] = sbb, hq[j][4] = sab;
             const int oy = oy0 + r - (WIN - 1);
             if (r >= WIN - 1 && oy < H2) {  // ring slot of marched row r - (WIN - 1) + k is (j + 1 + k) % WIN
-                float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+                float v[5];
 #pragma unroll
-                for (int k = 0; k < WIN; k++) {
+                for (int q = 0; q < 5; q++) v[q] = win.g[0] * hq[(j + 1) % WIN][q];
+#pragma unroll
+                for (int k = 1; k < WIN; k++) {
 #pragma unroll
                     for (int q = 0; q < 5; q++) v[q] += win.g[k] * hq[(j + 1 + k) % WIN][q];
                 }
@@ -146,18 +176,27 @@ __global__ __launch_bounds__(192) void k_ssim_forward(const float *__restrict__ 
                     const float sxx = fmaxf(sxx_raw, 0.0f), syy = fmaxf(v[3] - mu_yy, 0.0f), sxy = v[4] - mu_xy;
                     const float A1 = mu_xy * 2.0f + kC1, A2 = sxy * 2.0f + kC2;
                     const float B1 = mu_xx + mu_yy + kC1, B2 = sxx + syy + kC2;
-                    const float inv = 1.0f / (B1 * B2);
+                    // B1 >= C1, B2 >= C2: v_rcp_f32 (1 ulp) twice instead of three IEEE divisions (10 instructions each)
+                    const float i1 = __builtin_amdgcn_rcpf(B1), i2 = __builtin_amdgcn_rcpf(B2);
+                    const float inv = i1 * i2;
                     const float m = A1 * A2 * inv;
                     msum += m;
                     const float d_eab = 2.0f * A1 * inv;
-                    const float d_eaa = sxx_raw >= 0.0f ? -m / B2 : 0.0f;  // clamp_min(0) passes the gradient at >= 0
-                    const float d_mu = 2.0f * my * (A2 - A1) * inv - 2.0f * mx * (m / B1) - 2.0f * mx * d_eaa;
-                    const size_t o = (size_t)oy * W2 + ox;
-                    dmaps[(0 * 3 + ch) * plane + o] = d_mu * coef;
-                    dmaps[(1 * 3 + ch) * plane + o] = d_eaa * coef;
-                    dmaps[(2 * 3 + ch) * plane + o] = d_eab * coef;
+                    const float d_eaa = sxx_raw >= 0.0f ? -m * i2 : 0.0f;  // clamp_min(0) passes the gradient at >= 0
+                    const float d_mu = 2.0f * my * (A2 - A1) * inv - 2.0f * mx * (m * i1) - 2.0f * mx * d_eaa;
+                    float *drow = dmaps + (size_t)ch * plane + (size_t)oy * (uint32_t)W2;  // uniform
+                    st_off(drow, (uint32_t)ox * 4u, d_mu * coef);
+                    st_off(drow + (size_t)3u * plane, (uint32_t)ox * 4u, d_eaa * coef);
+                    st_off(drow + (size_t)6u * plane, (uint32_t)ox * 4u, d_eab * coef);
                 }
             }
+        }
+        if constexpr (WIN % 3 == 1) {
+            const Row t = pf[0];
+            pf[0] = pf[1], pf[1] = pf[2], pf[2] = t;
+        } else if constexpr (WIN % 3 == 2) {
+            const Row t = pf[2];
+            pf[2] = pf[1], pf[1] = pf[0], pf[0] = t;
         }
     }
     msum = wave_sum(msum), l1 = wave_sum(l1);
@@ -185,42 +224,51 @@ __global__ __launch_bounds__(192) void k_ssim_backward(const float *__restrict__
     const bool col_ok = ox >= 0 && ox < W2;
     const int px = px0 + l;
     const bool out_col = l < G::kOutCols && px < (int)w;
-    const size_t plane = (size_t)W2 * H2;
-    const float *d0 = dmaps + (0 * 3 + ch) * plane, *d1 = dmaps + (1 * 3 + ch) * plane, *d2 = dmaps + (2 * 3 + ch) * plane;
-    auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };
+    const uint32_t plane = (uint32_t)W2 * (uint32_t)H2;  // all element offsets fit 32 bits (checked by the host entry)
+    const float *d0 = dmaps + (0u * 3u + ch) * plane, *d1 = dmaps + (1u * 3u + ch) * plane, *d2 = dmaps + (2u * 3u + ch) * plane;
+    // l1_coef * sign(d): the sign bit of d on l1_coef, zero at d == 0
+    auto lsgn = [&](float d) { return d != 0.0f ? __builtin_copysignf(l1_coef, d) * 1.0f : 0.0f; };
     float hq[WIN][3];
     // marched row r: the three map values of the lane's column and (a, b, alpha pair) of the pixel the
     // iteration will emit (row py0 + r - (WIN - 1)); unconditional loads three rows ahead, as in the forward.
     const bool alpha_on = gt_channels == 4;
-    const int oxc = min(max(ox, 0), W2 - 1), pxc = min(px, (int)w - 1);
+    const uint32_t oxc = (uint32_t)min(max(ox, 0), W2 - 1), pxc = (uint32_t)min(px, (int)w - 1);
+    const uint32_t g_al = alpha_on ? 3u : 0u;
+    const bool alpha_row = alpha_on && ch == 0;  // the wave that writes v_pred's alpha
+    const uint32_t pc_a = (pxc * 4u + (uint32_t)ch) * 4u, pc_al = (pxc * 4u + 3u) * 4u;  // byte offsets
+    const uint32_t gc_a = (pxc * gt_channels + (uint32_t)ch) * 4u, gc_al = (pxc * gt_channels + g_al) * 4u;
+    const uint32_t oc = oxc * 4u;
     struct Row {
         float x0, x1, x2, a, b, pa, ga;
     };
-    auto fetch = [&](int r) {
+    auto fetch = [&](int r) {  // rows are wave-uniform: scalar pointers, per-lane constant column offsets
         const int oy = py0 - G::kOff + r;
         const bool ok = col_ok && oy >= 0 && oy < H2;
-        const size_t o = (size_t)min(max(oy, 0), H2 - 1) * W2 + oxc;
-        const size_t p = (size_t)min(max(py0 + r - (WIN - 1), 0), (int)h - 1) * w + pxc;
+        const size_t orow = (size_t)(uint32_t)min(max(oy, 0), H2 - 1) * (uint32_t)W2;
+        const uint32_t pyc = (uint32_t)min(max(py0 + r - (WIN - 1), 0), (int)h - 1);
+        const float *prow = pred + (size_t)pyc * w * 4u;
+        const float *grow = gt + (size_t)pyc * w * gt_channels;
         Row v;
-        v.x0 = d0[o], v.x1 = d1[o], v.x2 = d2[o];
-        v.a = pred[p * 4 + ch], v.b = gt[p * gt_channels + ch];
-        v.pa = pred[p * 4 + 3], v.ga = gt[p * gt_channels + (alpha_on ? 3 : 0)];
+        v.x0 = ld_off(d0 + orow, oc), v.x1 = ld_off(d1 + orow, oc), v.x2 = ld_off(d2 + orow, oc);
+        v.a = ld_off(prow, pc_a), v.b = ld_off(grow, gc_a);
+        v.pa = v.ga = 0.0f;
+        if (alpha_row) v.pa = ld_off(prow, pc_al), v.ga = ld_off(grow, gc_al);  // wave-uniform
         v.x0 = ok ? v.x0 : 0.0f, v.x1 = ok ? v.x1 : 0.0f, v.x2 = ok ? v.x2 : 0.0f;
         return v;
     };
-    Row c0 = fetch(0), c1 = fetch(1), c2 = fetch(2);
+    Row pf[3] = {fetch(0), fetch(1), fetch(2)};  // ring turned once per unrolled body, as in the forward
     for (int r0 = 0; r0 < G::kSegRows + WIN - 1; r0 += WIN) {
 #pragma unroll
         for (int j = 0; j < WIN; j++) {
             const int r = r0 + j;
-            rows[ch][0][l] = c0.x0, rows[ch][1][l] = c0.x1, rows[ch][2][l] = c0.x2;
-            const float a = c0.a, b = c0.b, pa = c0.pa, ga = c0.ga;
-            c0 = c1, c1 = c2;
-            c2 = fetch(r + 3);
+            const Row c = pf[j % 3];
+            rows[ch][0][l] = c.x0, rows[ch][1][l] = c.x1, rows[ch][2][l] = c.x2;
+            const float a = c.a, b = c.b, pa = c.pa, ga = c.ga;
+            pf[j % 3] = fetch(r + 3);
             wave_lds_sync();
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            float s0 = win.g[0] * rows[ch][0][l], s1 = win.g[0] * rows[ch][1][l], s2 = win.g[0] * rows[ch][2][l];
 #pragma unroll
-            for (int k = 0; k < WIN; k++) {
+            for (int k = 1; k < WIN; k++) {
                 s0 += win.g[k] * rows[ch][0][l + k];
                 s1 += win.g[k] * rows[ch][1][l + k];
                 s2 += win.g[k] * rows[ch][2][l + k];
@@ -229,17 +277,26 @@ __global__ __launch_bounds__(192) void k_ssim_backward(const float *__restrict__
             hq[j][0] = s0, hq[j][1] = s1, hq[j][2] = s2;
             const int py = py0 + r - (WIN - 1);
             if (r >= WIN - 1 && py < (int)h && out_col) {
-                float t[3] = {0.f, 0.f, 0.f};
+                float t[3];
 #pragma unroll
-                for (int k = 0; k < WIN; k++) {
+                for (int q = 0; q < 3; q++) t[q] = win.g[0] * hq[(j + 1) % WIN][q];
+#pragma unroll
+                for (int k = 1; k < WIN; k++) {
 #pragma unroll
                     for (int q = 0; q < 3; q++) t[q] += win.g[k] * hq[(j + 1 + k) % WIN][q];
                 }
-                const size_t p = (size_t)py * w + px;
-                v_pred[p * 4 + ch] = t[0] + 2.0f * a * t[1] + b * t[2] + l1_coef * sgn(a - b);
+                float *vrow = v_pred + (size_t)(uint32_t)py * w * 4u;  // uniform
+                st_off(vrow, ((uint32_t)px * 4u + (uint32_t)ch) * 4u, t[0] + 2.0f * a * t[1] + b * t[2] + lsgn(a - b));
                 if (ch == 0)  // alpha: compared only when the target has alpha (train.rs:248-252)
-                    v_pred[p * 4 + 3] = alpha_on ? l1_coef * sgn(pa - ga) : 0.0f;
+                    st_off(vrow, ((uint32_t)px * 4u + 3u) * 4u, alpha_on ? lsgn(pa - ga) : 0.0f);
             }
+        }
+        if constexpr (WIN % 3 == 1) {
+            const Row t = pf[0];
+            pf[0] = pf[1], pf[1] = pf[2], pf[2] = t;
+        } else if constexpr (WIN % 3 == 2) {
+            const Row t = pf[2];
+            pf[2] = pf[1], pf[1] = pf[0], pf[0] = t;
         }
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && ch == 0) {
@@ -430,6 +487,7 @@ extern "C" int brush_l1_ssim_loss(const float *pred, const float *gt, uint32_t w
     if (!pred || !gt || !loss || !v_pred || !workspace || w == 0 || h == 0) return BRUSH_ERR_INVALID_ARG;
     if (gt_channels != 3 && gt_channels != 4) return BRUSH_ERR_INVALID_ARG;
     if (ssim_weight > 0.0f && !window_ok(ssim_window)) return BRUSH_ERR_INVALID_ARG;  // odd sizes 3..15
+    if (9ull * (w + 2ull) * (h + 2ull) >= (1ull << 32)) return BRUSH_ERR_INVALID_ARG;   // 32-bit element offsets (477 M pixels)
     size_t need = 0;
     brush_loss_workspace_size(w, h, &need);
     if (workspace_bytes < need) return BRUSH_ERR_WORKSPACE_SMALL;
