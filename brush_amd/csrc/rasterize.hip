@@ -439,7 +439,11 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
                 const float nopac = -lds.opac[t];
                 const float scale = k >= 5u ? 1.0f : ((k == 2u || k == 4u) ? 0.5f * nopac : nopac);
                 const float val = sum * scale;
+#ifdef BRUSH_ELIM_NO_ATOMICS  // elimination timing (profiles/): everything but the atomic itself
+                if (val == 12345.678f) v_compact[(size_t)lds_gid[t] * kCompactStride + k] = val;
+#else
                 if (val != 0.0f) unsafeAtomicAdd(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], val);
+#endif
             }
         };
         // One record: its LDS row is read one record AHEAD (software pipeline, two register sets in turn), so the
@@ -512,6 +516,12 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
                 }
             }
             if (ballot64(contributed) != 0ull) {  // wave-uniform: all 64 lanes take part in the reduction
+#ifdef BRUSH_ELIM_NO_REDUCE  // elimination timing (profiles/): no staging, no reduction, no flush
+                if (!DET) {
+                    if (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7] + g[8] == 12345.678f) v_compact[lane] = g[0];
+                    return;
+                }
+#endif
                 if constexpr (!DET) {
                     // park the lane partials as 9 rows of the stage: plain LDS stores, no cross-lane VALU work
                     float *dst = stage + staged * (kGradComps * kRowWords) + lane;
