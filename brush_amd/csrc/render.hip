@@ -137,7 +137,7 @@ bool uniforms_ok(const BrushUniforms *u) {
 
 using namespace brush;
 
-extern "C" const char *brush_version(void) { return "brush_amd 0.2.0 (gfx950)"; }
+extern "C" const char *brush_version(void) { return "brush_amd 0.3.0 (gfx950)"; }
 
 extern "C" const char *brush_status_string(int status) {
     switch (status) {
