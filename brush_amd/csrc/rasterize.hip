@@ -666,8 +666,10 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
             const uint32_t cost = ceil_div(units, simds * k) * k;  // in wave-rounds per SIMD
             if (cost < best_cost) best_cost = cost, best_k = k;
         }
-        if (best_k >= max_k_regs) return 0u;                    // the registers stop the (k+1)-th workgroup
-        const uint32_t per_wg = (kLdsPerCu / best_k) & ~1023u;  // (k + 1) of these do not fit
+        if (best_k >= max_k_regs) return 0u;  // the registers stop the (k+1)-th workgroup
+        // halfway between "k + 1 fit" and "k fit": sized to the last KB (160 KB / k) the CU admitted one workgroup fewer
+        // than intended (per-wave timeline: 2 resident waves per SIMD instead of 3)
+        const uint32_t per_wg = ((kLdsPerCu / (best_k + 1u) + kLdsPerCu / best_k) / 2u) & ~1023u;
         return per_wg > static_lds ? per_wg - static_lds : 0u;
     };
 #define BRUSH_RASTER_BWD(NQ, DET, UNSORTED, ROWS)                                                                     \

@@ -2,7 +2,7 @@
 """A/B aid: per-stage times (hipEvents, eager launches) and the graph-replay step time of one named workload, for
 comparing builds or environment switches (e.g. BRUSH_PB_HANDBACK=0/1) process by process.
 
-    python tools/ab_stage.py S3 [steps]      # workloads: S1, dense, c3, S3
+    python tools/ab_stage.py S3 [steps]      # workloads: S1, mid (3072 tiles), hd (3600 tiles), dense, c3, S3
 """
 import json
 import math
@@ -19,7 +19,8 @@ from brush_amd import render as R  # noqa: E402
 from brush_amd.profiler import StageProfiler  # noqa: E402
 from brush_amd.synthetic import synthetic_cloud  # noqa: E402
 
-CFG = {"S1": (1 << 20, 1920, 1080, 3, 1.0, None), "dense": (1 << 20, 1920, 1080, 3, 0.25, None),
+CFG = {"S1": (1 << 20, 1920, 1080, 3, 1.0, None), "mid": (1 << 19, 1024, 768, 3, 1.0, None),
+       "hd": (1 << 19, 1280, 720, 3, 1.0, None), "dense": (1 << 20, 1920, 1080, 3, 0.25, None),
        "c3": (3_000_000, 1920, 1080, 3, 0.12, 40_000_000), "S3": (20_971_520, 3840, 2160, 3, 1.0, 24_000_000)}
 name = sys.argv[1] if len(sys.argv) > 1 else "S1"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
