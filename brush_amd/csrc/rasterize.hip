@@ -627,10 +627,14 @@ hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
     return hipGetLastError();
 }
 
-// Quadrants per wave of the backward: fewer waves per tile keep the per-record wave reduction rare (measured at 1080p:
-// 4 quadrants per wave 152 us, 2: 241 us, 1: 389 us), more waves per tile fill the chip when the frame has few tiles.
+// Quadrants per wave of the backward: fewer waves per tile mean less repeated per-record work (staging, set-up and
+// reduction run once per wave and record), more waves per tile fill the chip when the frame has few tiles.  Thresholds
+// from a sweep of frame sizes with the LDS-transposed reduction (backward kernel, us, 1 / 2 / 4 quadrants per wave;
+// profiles/r03_bwd_occupancy_schedule_experiment.json): 972 tiles 42 / 48 / 73, 1200: 56 / 46 / 66, 1728: 56 / 47 / 58,
+// 2040: 60 / 45 / 48, 2500: 70 / 68 / 66 (dense scene 283 / 177 / 129), 3072: 78 / 59 / 52, 3600: 97 / 61 / 47,
+// 4096: 141 / 121 / 112.  (With round 2's reduction the switch to one wave per tile paid only from 6144 tiles.)
 static uint32_t backward_quadrants_per_wave(uint32_t tiles) {
-    return tiles >= 6144u ? 4u : (tiles >= 2048u ? 2u : 1u);
+    return tiles >= 2304u ? 4u : (tiles >= 1100u ? 2u : 1u);
 }
 
 hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,

@@ -20,7 +20,10 @@ from brush_amd.profiler import StageProfiler  # noqa: E402
 from brush_amd.synthetic import synthetic_cloud  # noqa: E402
 
 CFG = {"S1": (1 << 20, 1920, 1080, 3, 1.0, None), "mid": (1 << 19, 1024, 768, 3, 1.0, None),
-       "hd": (1 << 19, 1280, 720, 3, 1.0, None), "dense": (1 << 20, 1920, 1080, 3, 0.25, None),
+       "hd": (1 << 19, 1280, 720, 3, 1.0, None), "sq1k": (1 << 20, 1024, 1024, 3, 1.0, None),
+       "sq512": (1 << 20, 512, 512, 3, 1.0, None), "t2040": (1 << 19, 960, 540, 3, 1.0, None),
+       "t2500": (1 << 19, 800, 800, 3, 1.0, None), "t1728": (1 << 19, 768, 576, 3, 1.0, None),
+       "t972": (1 << 19, 576, 432, 3, 1.0, None), "t2500d": (1 << 20, 800, 800, 3, 0.25, None), "vga": (1 << 19, 640, 480, 3, 1.0, None), "dense": (1 << 20, 1920, 1080, 3, 0.25, None),
        "c3": (3_000_000, 1920, 1080, 3, 0.12, 40_000_000), "S3": (20_971_520, 3840, 2160, 3, 1.0, 24_000_000)}
 name = sys.argv[1] if len(sys.argv) > 1 else "S1"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
