@@ -263,6 +263,25 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     return v;
 }
 
+#ifdef BRUSH_BWD_TRACE  // development build (make trace): per-wave timeline of the compositing backward, read by
+// tools/debug/bwd_timeline.py through brush_debug_read_bwd_trace
+__device__ uint64_t g_bwd_trace[16384 * 4];
+struct BwdTrace {
+    uint64_t t0;
+    uint32_t wid, recs;
+    __device__ ~BwdTrace() {
+        if (lane_id() == 0 && wid < 16384u) {
+            uint32_t hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_bwd_trace[wid * 4 + 0] = t0;
+            g_bwd_trace[wid * 4 + 1] = (uint64_t)wall_clock64();
+            g_bwd_trace[wid * 4 + 2] = ((uint64_t)xcc << 32) | hwid;
+            g_bwd_trace[wid * 4 + 3] = ((uint64_t)1 << 48) | ((uint64_t)recs << 24);
+        }
+    }
+};
+#endif
 // Staged records of the backward, one array per field (the forward's QuadRec pads the opacity to 16 bytes).
 struct BwdRecs {
     float4 a[kBatch];    // mean.x, mean.y, conic.x, conic.y
@@ -318,6 +337,9 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
     const uint32_t tile_id = unit / kWavesPerTile, sub = unit % kWavesPerTile;
     if (tile_id >= num_tiles) return;
     const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
+#ifdef BRUSH_BWD_TRACE
+    const BwdTrace trace{(uint64_t)wall_clock64(), blockIdx.x * TPB + wv, r1 > r0 ? r1 - r0 : 0u};
+#endif
     if (r1 <= r0) return;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t tx0 = (tile_id % tbx) * kTileWidth, ty0 = (tile_id / tbx) * kTileWidth;
@@ -702,3 +724,9 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
 }
 
 }  // namespace brush
+
+#ifdef BRUSH_BWD_TRACE
+extern "C" int brush_debug_read_bwd_trace(uint64_t *out, size_t words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(brush::g_bwd_trace), words * 8);
+}
+#endif

@@ -1,4 +1,5 @@
-"""Development aid: per-wave timeline of the compositing backward (needs libbrush_hip_trace.so, BRUSH_BWD_TRACE)."""
+"""Development aid: per-wave timeline of the compositing backward (needs `make -C brush_amd/csrc trace`:
+libbrush_hip_trace.so, built with BRUSH_BWD_TRACE)."""
 import ctypes, math, sys, os, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
