@@ -70,14 +70,30 @@ struct Carver {
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
+// Wave64 inclusive prefix sum on the VALU: six DPP adds (row_shr 1/2/4/8 inside each row of 16 lanes, then
+// row_bcast:15 / row_bcast:31 carry the row totals up).  __shfl_up is a ds_bpermute on gfx950 (LDS crossbar, ~60 cycles of
+// latency each, six of them in a dependent chain): the in-kernel timeline of the small kernels (profiles/
+// r04_small_kernel_timeline.json) showed those chains as a large share of every scan / reservation / ranking phase.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+    // lanes whose source lane does not exist, and rows outside ROW_MASK, add `old` = 0
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d, 64);
-        if ((int)lane_id() >= d) v += o;
-    }
+    v = dpp_add_u32<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add_u32<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add_u32<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add_u32<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add_u32<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+    v = dpp_add_u32<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
     return v;
 }
+// Value of lane `src` (compile-time or wave-uniform) in every lane, through the scalar unit (v_readlane_b32).
+__device__ __forceinline__ uint32_t wave_bcast(uint32_t v, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src);
+}
+// Sum over the wave, in every lane.
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return wave_bcast(wave_inclusive_scan(v), 63u); }
 
 // ---- internal launch API (one per translation unit) ----------------------------------
 // scan.hip

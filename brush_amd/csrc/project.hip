@@ -22,6 +22,7 @@
 // All kernels are HBM-streaming (roofline: HBM).
 #include "internal.hpp"
 #include "splat_math.hpp"
+#include "trace.hpp"
 
 #pragma clang fp contract(off)
 
@@ -170,7 +171,7 @@ __device__ __forceinline__ void walk_flat(uint32_t area, const uint32_t bb[4], c
     late_reset(ring, st);
     const uint32_t incl = wave_inclusive_scan(area);
     const uint32_t excl = incl - area;
-    const uint32_t total = __shfl(incl, 63, 64);
+    const uint32_t total = wave_bcast(incl, 63u);
     for (uint32_t base = 0; base < total; base += kWave) {  // wave-uniform
         const uint32_t j = base + lane;
         // owner = number of lanes whose inclusive prefix is <= j (prefixes are non-decreasing)
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                                            uint32_t *__restrict__ walk_counter) {
     __shared__ uint32_t wave_cnt[kThreads / kWave];
     __shared__ uint32_t vis_list[kThreads / kWave][kCullPerThread * kWave];  // per wave: global ids that passed
+    BRUSH_KTRACE(kTrCull, 0);
     // (Measured and rejected, round 3: streaming the raw opacities with Phase A's coalesced loads instead of gathering
     // them in Phase B, where every candidate's 4 bytes cost a 128-byte request: +1.5 us at 1 M splats, no gain at 21 M.)
     const uint32_t gt = blockIdx.x * kThreads + threadIdx.x;
@@ -348,6 +350,8 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
             smax_r[r] = 0.0f;
         }
     }
+    BRUSH_KTRACE_MARK(1, mean_r[0][0]);
+    BRUSH_KTRACE_MARK(2, smax_r[kCullPerThread - 1]);
     uint32_t n_cand = 0;
     uint32_t *list = vis_list[threadIdx.x / kWave];
 #pragma unroll
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
 
     // Phase B — exact cull (project_forward.wgsl:36-66) and, for the splats that pass, the whole
     // ProjectedSplat record (project_visible.wgsl:163-258).
+    BRUSH_KTRACE_MARK(3, n_cand);
     uint32_t block_visible = 0;
     for (uint32_t base = 0; base < n_cand; base += kWave) {  // wave-uniform
         const uint32_t i = base + lane_id();
@@ -421,6 +426,7 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
         }
         block_visible += __popcll(__ballot(visible));
     }
+    BRUSH_KTRACE_MARK(4, block_visible);
     if (lane_id() == 0) wave_cnt[threadIdx.x / kWave] = block_visible;
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
@@ -466,22 +472,28 @@ __global__ __launch_bounds__(kThreads) void k_compact(uint32_t n, const uint32_t
     __shared__ uint32_t wave_cnt[kCullPerThread][kThreads / kWave];
     __shared__ uint32_t pre_s[kThreads / kWave];
     const uint32_t wid = threadIdx.x / kWave;
-    uint32_t before = 0;
-    if (SELF_SCAN) {
-        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kThreads) before += block_offsets[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
-        if (lane_id() == 0) pre_s[wid] = before;
-    }
+    BRUSH_KTRACE(kTrCompact, 0);
+    // the keys do not depend on the block offsets: requested first, so both loads are in flight together
     uint32_t key[kCullPerThread];
-    uint64_t bal[kCullPerThread];
 #pragma unroll
     for (uint32_t r = 0; r < kCullPerThread; r++) {
         const uint32_t g = blockIdx.x * kCullBlock + r * kThreads + threadIdx.x;
         key[r] = g < n ? key_all[g] : kInvalid;
+    }
+    uint32_t before = 0;
+    if (SELF_SCAN) {
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kThreads) before += block_offsets[i];
+        BRUSH_KTRACE_MARK(1, before);
+        before = wave_sum(before);
+        if (lane_id() == 0) pre_s[wid] = before;
+    }
+    uint64_t bal[kCullPerThread];
+#pragma unroll
+    for (uint32_t r = 0; r < kCullPerThread; r++) {
         bal[r] = __ballot(key[r] != kInvalid);
         if (lane_id() == 0) wave_cnt[r][wid] = __popcll(bal[r]);
     }
+    BRUSH_KTRACE_MARK(2, key[kCullPerThread - 1]);
     __syncthreads();
     uint32_t off;
     if (SELF_SCAN) {
@@ -518,7 +530,9 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
     ViewParams vp, const float4 *__restrict__ proj_global, const uint32_t *__restrict__ num_visible,
     uint32_t *__restrict__ global_from_compact, uint32_t *__restrict__ compact_from_global,
     float *__restrict__ projected, uint32_t *__restrict__ tiles_hit, WalkQueue q, uint32_t small_switch) {
+    BRUSH_KTRACE(kTrProjectVisible, 0);
     const uint32_t V = *num_visible;
+    BRUSH_KTRACE_MARK(1, V);
     const uint32_t n = vp.total_splats;
     const uint32_t small_area = V > small_switch ? kSmallAreaMany : kSmallArea;
     // Tail of global_from_compact_gid (never written by the sort) := 0.
@@ -550,6 +564,7 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
             conic[0] = r0.z, conic[1] = r0.w, conic[2] = r1.x;
             opac = r1.y;
             rgb[0] = r2.x, rgb[1] = r2.y, rgb[2] = r2.z;
+            BRUSH_KTRACE_MARK(2, r0.x + r2.z);
             tt = make_tile_test(conic, opac);
             walk_rect(xy, conic, tt, make_tile_reach(tt), vp.tile_bounds, bb);
         }
@@ -558,19 +573,31 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
         const uint32_t bbox_tiles = active ? (bb[2] - bb[0]) * (bb[3] - bb[1]) : 0u;
         const uint32_t nchunks = bbox_tiles > small_area ? (bbox_tiles + kChunkTiles - 1) / kChunkTiles : 0u;
         const uint32_t incl = wave_inclusive_scan(nchunks);
-        const uint32_t wave_total = __shfl(incl, 63, 64);
+        const uint32_t wave_total = wave_bcast(incl, 63u);
         // ... and ONE atomicAdd per workgroup: the returning atomics of all workgroups hit one address and are
-        // executed one after the other
+        // executed one after the other (~88 per us: 800 workgroups at the headline scene take 9 us to drain).  The
+        // atomic is issued here and its result is first read after the inline walk below, which covers that wait
+        // (profiles/r04_small_kernel_timeline.json: 2.1 us of every wave's 10 us stood between the two).
         if (lane_id() == 0) wave_chunks[wv] = wave_total;
         __syncthreads();
+        uint32_t block_base = 0;
         if (threadIdx.x == 0) {
             const uint32_t tot = (wave_chunks[0] + wave_chunks[1]) + (wave_chunks[2] + wave_chunks[3]);
-            block_base_s = tot ? atomicAdd(q.counter, tot) : 0u;
+            if (tot) block_base = atomicAdd(q.counter, tot);
         }
+        uint32_t wave_before = 0;
+        for (uint32_t w2 = 0; w2 < wv; w2++) wave_before += wave_chunks[w2];
+        // small bboxes: flattened across the wave
+        const bool small = active && bbox_tiles <= small_area;
+        uint32_t flat_cnt;
+        uint64_t flat_mask;
+        walk_flat(small ? bbox_tiles : 0u, bb, tt, xy, 0u, flat_cnt, flat_mask, rings[wv]);
+        BRUSH_KTRACE_MARK(4, flat_cnt);
+        if (threadIdx.x == 0) block_base_s = block_base;
         __syncthreads();
-        uint32_t wave_base = block_base_s;
-        for (uint32_t w2 = 0; w2 < wv; w2++) wave_base += wave_chunks[w2];
-        __syncthreads();  // the next trip overwrites both
+        const uint32_t wave_base = block_base_s + wave_before;
+        BRUSH_KTRACE_MARK(3, wave_base);
+        __syncthreads();  // the next trip overwrites wave_chunks and block_base_s
         uint32_t area = 0, slot = kInvalid;
         if (nchunks) {
             const uint32_t first = wave_base + incl - nchunks;
@@ -583,11 +610,6 @@ __global__ __launch_bounds__(kThreads) void k_project_visible(
                 for (uint32_t k = first; k < q.capacity; k++) q.items[k] = make_uint2(kInvalid, 0u);
             }
         }
-        // small bboxes: flattened across the wave
-        const bool small = active && bbox_tiles <= small_area;
-        uint32_t flat_cnt;
-        uint64_t flat_mask;
-        walk_flat(small ? bbox_tiles : 0u, bb, tt, xy, 0u, flat_cnt, flat_mask, rings[wv]);
         if (small) {
             area = flat_cnt;
             slot = kInlineFlag;
@@ -629,7 +651,9 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
                                                          WalkQueue q, uint32_t *__restrict__ tiles_hit) {
     __shared__ LateRing rings[kThreads / kWave];
     LateRing &ring = rings[threadIdx.x / kWave];
+    BRUSH_KTRACE(kTrWalkCount, 0);
     const uint32_t n_items = min(*q.counter, q.capacity);
+    BRUSH_KTRACE_MARK(1, n_items);
     const uint32_t G = walk_group(n_items);
     const uint32_t n_groups = (n_items + G - 1) / G;
     const uint32_t lane = lane_id();
@@ -648,6 +672,7 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
         s.b0 = s.b1 = s.area = 0u;
         s.bw = 1u;
         if (valid) s = load_walk(vp, projected, item.x);
+        BRUSH_KTRACE_MARK(2, s.area + item.x);
         const uint32_t first = item.y * kChunkTiles;
         const uint32_t len = (valid && first < s.area) ? min(s.area - first, kChunkTiles) : 0u;
         uint64_t my_mask = 0;
@@ -676,6 +701,7 @@ __global__ __launch_bounds__(kThreads) void k_walk_count(ViewParams vp, const fl
         }
         my_mask |= late_flush(ring, st);
         const uint32_t my_cnt = (uint32_t)__popcll(my_mask);
+        BRUSH_KTRACE_MARK(3, my_cnt);
         const uint32_t pre = wave_inclusive_scan(lane < G ? my_cnt : 0u);
         if (mine) {
             q.chunk_count[it] = pre;
@@ -758,7 +784,7 @@ __device__ __forceinline__ void map_inline_role(uint32_t bid, uint32_t nblocks, 
         } else {
             const uint32_t cnt = (uint32_t)__popcll(mask);
             const uint32_t incl = wave_inclusive_scan(cnt), excl = incl - cnt;
-            const uint32_t total = __shfl(incl, 63, 64);
+            const uint32_t total = wave_bcast(incl, 63u);
             const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
             for (uint32_t base = 0; base < total; base += kWave) {  // wave-uniform
                 const uint32_t j = base + lane;
@@ -862,6 +888,7 @@ __global__ __launch_bounds__(kThreads) void k_map_intersects(ViewParams vp, cons
                                                              uint32_t *__restrict__ tile_ids,
                                                              uint32_t *__restrict__ gids, WalkQueue q,
                                                              uint32_t inline_blocks) {
+    BRUSH_KTRACE(kTrMap, blockIdx.x < inline_blocks ? 0u : (1u << 24) | 1u);
     if (blockIdx.x < inline_blocks)
         map_inline_role(blockIdx.x, inline_blocks, vp, projected, cum_tiles_hit, num_visible, cap, tile_ids, gids, q);
     else

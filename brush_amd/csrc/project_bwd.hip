@@ -21,6 +21,7 @@
 // Compiled with -ffp-contract=off (same expression trees as the forward projection).
 #include "internal.hpp"
 #include "splat_math.hpp"
+#include "trace.hpp"
 
 #pragma clang fp contract(off)
 
@@ -63,7 +64,9 @@ __device__ __forceinline__ void cov2d_to_conic_vjp(const float conic[3], const f
 
 __global__ __launch_bounds__(kThreads) void k_zero_compact_grads(const uint32_t *__restrict__ num_visible,
                                                                  uint32_t n, float4 *__restrict__ v_compact) {
+    BRUSH_KTRACE(kTrZeroGrads, 0);
     const uint32_t V = min(*num_visible, n);
+    BRUSH_KTRACE_MARK(1, V);
     const uint32_t words = V * (kCompactStride / 4);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x)
         v_compact[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     constexpr uint32_t kStageA = (kWave * kRowPad > 512u ? kWave * kRowPad : 512u);
     constexpr uint32_t kStageFloats = kStageA > kWave * kRes ? kStageA : kWave * kRes;
     __shared__ float stage_all[kThreads / kWave][kStageFloats];
+    BRUSH_KTRACE(kTrProjectBwd, 0);
     const uint32_t wv = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     float *stage = stage_all[wv];

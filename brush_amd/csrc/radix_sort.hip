@@ -29,6 +29,7 @@
 // Traffic per pass: 4 B/key (upsweep) + 16 B/pair (downsweep).  Roofline: HBM at large n, kernel
 // boundaries at n ~ 100 k.  The pass structure sorts exactly the reference's 4*ceil(bits/4) low bits.
 #include "common.hpp"
+#include "trace.hpp"
 
 namespace brush {
 namespace {
@@ -46,6 +47,13 @@ constexpr uint32_t kFusedMaxTiles = 512;
 // lane whose LDS image (74 KiB) lets TWO of them share a CU, so one's loads and stores overlap the other's ranking.
 constexpr uint32_t kBigTileKeys = 8192;
 constexpr uint32_t kBigThreads = 512;
+// FUSED scatter: count-table rows every thread requests before the element count has arrived (4 quarters x 32 rows =
+// the first kSortTargetTiles rows)
+// Thread (group g8 = tid / 128, digit pair dp = tid % 128) owns rows g8 + 8 j of the 16-bit table: 16 dword loads
+// cover digits 2 dp and 2 dp + 1 of the first 128 rows (32 registers of 32-bit counts spilled the 16-key variant).
+constexpr uint32_t kSpecRows = 16;
+constexpr uint32_t kTableGroups = 8;
+static_assert(kTableGroups * kSpecRows == kSortTargetTiles, "the table always has the speculatively loaded rows");
 
 // Keys per lane for a sort of n keys: smallest power of two K in [1,16] with n / (1024 K) <= 128.
 __host__ __device__ __forceinline__ uint32_t sort_items(uint32_t n) {
@@ -68,7 +76,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_upsweep(const uint32_t *_
                                                               const uint32_t *__restrict__ d_n, uint32_t max_n,
                                                               uint32_t shift, uint32_t mask,
                                                               uint32_t *__restrict__ counts, uint32_t max_tiles) {
+    BRUSH_KTRACE(kTrSortUp, shift | (((shift >> 3) + (max_n > (1u << 21) ? 4u : 0u)) << 24));
     const uint32_t n = min(*d_n, max_n);
+    BRUSH_KTRACE_MARK(1, n);
     const uint32_t items = FUSED ? sort_items(n) : kBigTileKeys / kSortThreads;
     const uint32_t tile_keys = kSortThreads * items;
     const uint32_t tile = blockIdx.x;
@@ -80,15 +90,21 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_upsweep(const uint32_t *_
     const uint32_t base = tile * tile_keys;
     for (uint32_t i = 0; i < items; i++) {
         const uint32_t idx = base + i * kSortThreads + threadIdx.x;
-        if (idx < n) atomicAdd(&hist[wid][(keys[idx] >> shift) & mask], 1u);
+        if (idx < n) {
+            const uint32_t k = keys[idx];
+            if (i == 0) BRUSH_KTRACE_MARK(2, k);
+            atomicAdd(&hist[wid][(k >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
+    BRUSH_KTRACE_MARK(3, n);
     if (threadIdx.x < kRadix) {
         const uint32_t d = threadIdx.x;
         uint32_t c = 0;
 #pragma unroll
         for (uint32_t w = 0; w < kSortWaves; w++) c += hist[w][d];
-        if (FUSED) counts[(size_t)tile * kRadix + d] = c;
+        // FUSED: 16-bit counts (a tile holds at most 16384 keys), row = 128 dwords of digit pairs
+        if (FUSED) reinterpret_cast<uint16_t *>(counts)[(size_t)tile * kRadix + d] = (uint16_t)c;
         else counts[(size_t)d * max_tiles + tile] = c;
     }
 }
@@ -129,11 +145,16 @@ struct DownLdsT {
     uint32_t wave_hist[WAVES][kRadix];
     uint32_t digit_base[kRadix];  // global position of the tile's first key of each digit
     uint32_t tile_start[kRadix];  // position inside the tile (after the reorder) of each digit's run
-    uint32_t part[PARTS][kRadix];     // FUSED: partial column sums (keys of earlier tiles), 4 tile-quarters
-    uint32_t part_all[PARTS][kRadix]; // FUSED: partial column sums over all tiles
     uint32_t wave_tot2[4][2];
+    // FUSED: partial column sums of the count table per row group (keys of earlier tiles / of all tiles).  They live
+    // from before barrier A to barrier C, the reordered pairs from barrier C on: same storage.
+    static_assert(2 * PARTS * kRadix <= TILE_KEYS, "part / part_all alias keys[]");
+    __device__ __forceinline__ uint32_t (*part())[kRadix] { return reinterpret_cast<uint32_t(*)[kRadix]>(keys); }
+    __device__ __forceinline__ uint32_t (*part_all())[kRadix] {
+        return reinterpret_cast<uint32_t(*)[kRadix]>(keys + PARTS * kRadix);
+    }
 };
-using DownLds = DownLdsT<kMaxTileKeys, kSortWaves, 4>;
+using DownLds = DownLdsT<kMaxTileKeys, kSortWaves, kTableGroups>;
 using DownLdsBig = DownLdsT<kBigTileKeys, kBigThreads / kWave, 1>;
 static_assert(2 * sizeof(DownLdsBig) <= 160 * 1024, "two large-sort workgroups per CU");
 
@@ -155,6 +176,48 @@ __device__ __forceinline__ void block_excl_scan256_pair(uint32_t &a, uint32_t &b
     a = oa, b = ob;
 }
 
+// Sums of the speculatively loaded count-table rows (thread = (group g8, digit pair dp), rows g8 + 8 j): keys of the
+// pair's digits in the tiles before `tile` / in all `num_tiles` tiles, as packed 16-bit-pair sums of at most 16 rows
+// each (16 * 16384 overflows 16 bits, so the halves are split before they are added up).
+struct PairSums {
+    uint32_t below[2], all[2];
+};
+// FUSED: the partial column sums of the [tile][digit] count table -> L.part() / L.part_all().  Rows 0 .. 127 were
+// requested by the kernel before it knew n (`spec`, masked here); the rest of a large table (more than 128 tiles: sorts
+// above 2 M keys) is read with kTableLoads independent row loads in flight per thread (latency-, not bandwidth-bound).
+template <typename LDS>
+__device__ __forceinline__ void table_sums_to_lds(const uint32_t (&spec)[kSpecRows], const uint32_t *__restrict__ counts,
+                                                  uint32_t tile, uint32_t num_tiles, LDS &L, KTraceRef trace) {
+    const uint32_t dp = threadIdx.x & (kRadix / 2 - 1), g8 = threadIdx.x / (kRadix / 2);
+    PairSums ps{};
+#pragma unroll
+    for (uint32_t j = 0; j < kSpecRows; j++) {
+        const uint32_t t = g8 + kTableGroups * j;
+        const uint32_t a = t < num_tiles ? spec[j] : 0u;
+        const uint32_t b = t < tile ? spec[j] : 0u;  // tile < num_tiles
+        ps.all[0] += a & 0xFFFFu, ps.all[1] += a >> 16;
+        ps.below[0] += b & 0xFFFFu, ps.below[1] += b >> 16;
+    }
+    constexpr uint32_t kTableLoads = 16;
+    for (uint32_t t0 = kTableGroups * kSpecRows + g8; t0 < num_tiles; t0 += kTableGroups * kTableLoads) {
+        uint32_t c[kTableLoads];
+#pragma unroll
+        for (uint32_t j = 0; j < kTableLoads; j++) {
+            const uint32_t t = t0 + kTableGroups * j;
+            c[j] = t < num_tiles ? counts[(size_t)t * (kRadix / 2) + dp] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kTableLoads; j++) {
+            const uint32_t b = (t0 + kTableGroups * j) < tile ? c[j] : 0u;
+            ps.all[0] += c[j] & 0xFFFFu, ps.all[1] += c[j] >> 16;
+            ps.below[0] += b & 0xFFFFu, ps.below[1] += b >> 16;
+        }
+    }
+    BRUSH_KTRACE_MARK_VIA(trace, 2, ps.below[0] + ps.all[1]);
+    L.part()[g8][2 * dp] = ps.below[0], L.part()[g8][2 * dp + 1] = ps.below[1];
+    L.part_all()[g8][2 * dp] = ps.all[0], L.part_all()[g8][2 * dp + 1] = ps.all[1];
+}
+
 template <bool FUSED, uint32_t ITEMS, uint32_t THREADS, typename LDS>
 __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys_in,
                                                const uint32_t *__restrict__ vals_in,
@@ -162,8 +225,9 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
                                                uint32_t n, uint32_t shift, uint32_t mask,
                                                const uint32_t *__restrict__ counts,
                                                const uint32_t *__restrict__ totals, uint32_t max_tiles,
-                                               uint32_t *__restrict__ edges, uint32_t edge_keys, LDS &L) {
-    static_assert(!FUSED || THREADS == kSortThreads, "the fused table sums assume 4 quarters of 256 threads");
+                                               uint32_t *__restrict__ edges, uint32_t edge_keys, LDS &L,
+                                               const uint32_t (&spec)[kSpecRows], KTraceRef trace = KTraceRef{}) {
+    static_assert(!FUSED || THREADS == kSortThreads, "the fused table sums assume 8 groups of 128 threads");
     constexpr uint32_t kTileKeys = THREADS * ITEMS;
     constexpr uint32_t kWaves = THREADS / kWave;
     // small sorts: the scatter is a few hundred KB, not worth two barriers — unless the pass also finds the run
@@ -178,44 +242,37 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
     // The loads are issued first so that they are in flight during the table sums below.
     const uint32_t tile_base = tile * kTileKeys;
     const uint32_t chunk = tile_base + wid * (kWave * ITEMS);
-    uint32_t key[ITEMS], val[ITEMS];
+    // Large tiles are register-bound (16 keys, 16 ranks and the ballot temporaries per lane): their values are loaded
+    // late, just before they are placed, instead of being held across the ranking.
+    constexpr bool kLateVals = ITEMS >= 8;
+    uint32_t key[ITEMS], val[kLateVals ? 1 : ITEMS];
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; i++) {
         const uint32_t idx = chunk + i * kWave + lane;
         key[i] = idx < n ? keys_in[idx] : 0u;
-        val[i] = idx < n ? (vals_in ? vals_in[idx] : idx) : 0u;  // vals_in == nullptr: the positions themselves
+        if constexpr (!kLateVals)
+            val[i] = idx < n ? (vals_in ? vals_in[idx] : idx) : 0u;  // vals_in == nullptr: the positions themselves
     }
-    // FUSED: counts[t][d]; thread (quarter qt, digit d) sums the rows t = qt, qt+4, ... of the ACTUAL tiles:
-    // keys of digit d in earlier tiles / in all tiles.
+    // FUSED: counts[t][d] (16-bit); the small-tile variants sum their share of the table now, behind the key loads
+    // issued above; for the large-tile variants (ITEMS >= 8, register-bound) the kernel did it before the switch.
     uint32_t glob_base = 0, glob_tot = 0;
     if (FUSED) {
-        const uint32_t num_tiles = (n + kTileKeys - 1) / kTileKeys;
-        const uint32_t d = threadIdx.x & (kRadix - 1), qt = threadIdx.x / kRadix;
-        uint32_t below = 0, all = 0;
-        // kTableLoads independent row loads in flight per thread: the loop is latency-, not bandwidth-bound
-        constexpr uint32_t kTableLoads = 16;
-        for (uint32_t t0 = qt; t0 < num_tiles; t0 += 4 * kTableLoads) {
-            uint32_t c[kTableLoads];
-#pragma unroll
-            for (uint32_t j = 0; j < kTableLoads; j++) {
-                const uint32_t t = t0 + 4 * j;
-                c[j] = t < num_tiles ? counts[(size_t)t * kRadix + d] : 0u;
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < kTableLoads; j++) {
-                all += c[j];
-                below += (t0 + 4 * j) < tile ? c[j] : 0u;
-            }
-        }
-        L.part[qt][d] = below;
-        L.part_all[qt][d] = all;
+        if constexpr (ITEMS < 8) table_sums_to_lds(spec, counts, tile, (n + kTileKeys - 1) / kTileKeys, L, trace);
     } else if (threadIdx.x < kRadix) {
         glob_tot = totals[threadIdx.x];
         glob_base = counts[(size_t)threadIdx.x * max_tiles + tile];
     }
     __syncthreads();  // A: wave_hist zeroed, partial column sums published
+    BRUSH_KTRACE_MARK_VIA(trace, 3, key[0]);
 
-    uint32_t rank[ITEMS];
+    // rank of a key among the keys of its digit inside its wave's chunk: < 64 * ITEMS <= 1024.  The large-tile variants
+    // are register-bound and keep two ranks per register.
+    constexpr bool kPackRanks = ITEMS >= 8;
+    uint32_t rank[kPackRanks ? ITEMS / 2 : ITEMS];
+    auto rank_of = [&](uint32_t i) -> uint32_t {
+        if constexpr (kPackRanks) return (rank[i / 2] >> ((i & 1u) * 16u)) & 0xFFFFu;
+        else return rank[i];
+    };
     const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; i++) {
@@ -238,7 +295,8 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
             L.wave_hist[wid][digit] = old + cnt;
         }
         old = __shfl(old, leader, 64);
-        rank[i] = old + below;
+        if constexpr (kPackRanks) rank[i / 2] = (i & 1u) ? (rank[i / 2] | ((old + below) << 16)) : (old + below);
+        else rank[i] = old + below;
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();  // B: every wave's digit counts are final
@@ -255,8 +313,8 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
             tile_cnt += t;
         }
         if (FUSED) {
-            glob_tot = (L.part_all[0][d] + L.part_all[1][d]) + (L.part_all[2][d] + L.part_all[3][d]);
-            glob_base = (L.part[0][d] + L.part[1][d]) + (L.part[2][d] + L.part[3][d]);
+#pragma unroll
+            for (uint32_t g = 0; g < kTableGroups; g++) glob_tot += L.part_all()[g][d], glob_base += L.part()[g][d];
         }
     }
     uint32_t smaller = glob_tot, run_start = tile_cnt;
@@ -266,15 +324,16 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
         L.tile_start[threadIdx.x] = run_start;
     }
     __syncthreads();  // C
+    BRUSH_KTRACE_MARK_VIA(trace, 4, smaller);
     if (!reorder) {
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
             const uint32_t idx = chunk + i * kWave + lane;
             if (idx < n) {
                 const uint32_t digit = (key[i] >> shift) & mask;
-                const uint32_t pos = L.digit_base[digit] + L.wave_hist[wid][digit] + rank[i];
+                const uint32_t pos = L.digit_base[digit] + L.wave_hist[wid][digit] + rank_of(i);
                 if (keys_out) keys_out[pos] = key[i];
-                vals_out[pos] = val[i];
+                vals_out[pos] = kLateVals ? (vals_in ? vals_in[idx] : idx) : val[kLateVals ? 0 : i];
             }
         }
         return;
@@ -285,9 +344,9 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
         const uint32_t idx = chunk + i * kWave + lane;
         if (idx < n) {
             const uint32_t digit = (key[i] >> shift) & mask;
-            const uint32_t lp = L.tile_start[digit] + L.wave_hist[wid][digit] + rank[i];
+            const uint32_t lp = L.tile_start[digit] + L.wave_hist[wid][digit] + rank_of(i);
             L.keys[lp] = key[i];
-            L.vals[lp] = val[i];
+            L.vals[lp] = kLateVals ? (vals_in ? vals_in[idx] : idx) : val[kLateVals ? 0 : i];
         }
     }
     __syncthreads();
@@ -295,7 +354,9 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
     // write consecutive global addresses (round 1 scattered one dword per lane into 256 runs: 2.1x write
     // amplification at the HBM counters)
     const uint32_t tile_n = min(kTileKeys, n - tile_base);
-#pragma unroll
+    // 16 keys per lane at 1024 threads (128 registers): fully unrolled it spills
+    constexpr uint32_t kOutUnroll = (ITEMS > 8 && THREADS == kSortThreads) ? 4 : ITEMS;
+#pragma unroll kOutUnroll
     for (uint32_t i = 0; i < ITEMS; i++) {
         const uint32_t lp = i * THREADS + threadIdx.x;
         if (lp < tile_n) {
@@ -327,20 +388,40 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ d_n,
     uint32_t max_n, uint32_t shift, uint32_t mask, const uint32_t *__restrict__ counts,
     const uint32_t *__restrict__ totals, uint32_t max_tiles, uint32_t *__restrict__ edges, uint32_t edge_keys) {
+    BRUSH_KTRACE(kTrSortDown, shift | (((shift >> 3) + (max_n > (1u << 21) ? 4u : 0u)) << 24));
+    // The first 128 rows of the [tile][digit] count table (every row a sort of up to 2 M keys has) are requested before
+    // the element count is known: the table sum used to start only when *d_n had arrived and took two dependent batches
+    // of loads (2.2 us of the kernel's 6.5 at 100 k keys, profiles/r04_small_kernel_timeline.json).  The table has at least
+    // kSortTargetTiles = 128 rows (sort_max_tiles); rows of tiles that do not exist hold leftovers and are masked in the body.
+    uint32_t spec[kSpecRows];
+    {
+        const uint32_t dp = threadIdx.x & (kRadix / 2 - 1), g8 = threadIdx.x / (kRadix / 2);
+#pragma unroll
+        for (uint32_t j = 0; j < kSpecRows; j++)
+            spec[j] = FUSED ? counts[(size_t)(g8 + kTableGroups * j) * (kRadix / 2) + dp] : 0u;
+    }
     const uint32_t n = min(*d_n, max_n);
+    BRUSH_KTRACE_MARK(1, n);
     const uint32_t items = sort_items(n);
     if ((uint64_t)blockIdx.x * kSortThreads * items >= n) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     DownLds &L = *reinterpret_cast<DownLds *>(lds_raw);
-#define BRUSH_DOWN(K)                                                                                             \
+#define BRUSH_DOWN(K, SPEC)                                                                                       \
     downsweep_body<FUSED, K, kSortThreads>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, counts, totals, \
-                                           max_tiles, edges, edge_keys, L)
-    switch (items) {  // block-uniform
-        case 1: BRUSH_DOWN(1); break;
-        case 2: BRUSH_DOWN(2); break;
-        case 4: BRUSH_DOWN(4); break;
-        case 8: BRUSH_DOWN(8); break;
-        default: BRUSH_DOWN(16); break;
+                                           max_tiles, edges, edge_keys, L, SPEC, BRUSH_KTRACE_REF)
+    if (items >= 8) {  // block-uniform
+        // large tiles are register-bound: the table sums are formed here, before their 8 / 16 keys per lane are live
+        table_sums_to_lds(spec, counts, blockIdx.x, (n + kSortThreads * items - 1) / (kSortThreads * items), L,
+                          BRUSH_KTRACE_REF);
+        const uint32_t none[kSpecRows] = {};
+        if (items == 8) BRUSH_DOWN(8, none);
+        else BRUSH_DOWN(16, none);
+        return;
+    }
+    switch (items) {
+        case 1: BRUSH_DOWN(1, spec); break;
+        case 2: BRUSH_DOWN(2, spec); break;
+        default: BRUSH_DOWN(4, spec); break;
     }
 #undef BRUSH_DOWN
 }
@@ -355,8 +436,10 @@ __global__ __launch_bounds__(kBigThreads) void k_sort_downsweep_big(
     if ((uint64_t)blockIdx.x * kBigTileKeys >= n) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     DownLdsBig &L = *reinterpret_cast<DownLdsBig *>(lds_raw);
+    const uint32_t no_spec[kSpecRows] = {};
     downsweep_body<false, kBigTileKeys / kBigThreads, kBigThreads>(keys_in, vals_in, keys_out, vals_out, n, shift,
-                                                                   mask, counts, totals, max_tiles, edges, edge_keys, L);
+                                                                   mask, counts, totals, max_tiles, edges, edge_keys, L,
+                                                                   no_spec);
 }
 
 __global__ void k_sort_copy(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "internal.hpp"
+#include "trace.hpp"
 
 namespace brush {
 namespace {
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_rasterize_quad(
     uint32_t *__restrict__ tile_bins, const uint32_t *__restrict__ bin_edges, const float *__restrict__ projected,
     void *__restrict__ out_img, uint32_t *__restrict__ final_index, uint32_t u32_pitch) {
     __shared__ QuadRec lds_all[kTilesPerBlock][kBatch];
+    BRUSH_KTRACE(kTrRasterize, 0);
     const uint32_t q = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     QuadRec *lds = lds_all[q];
     const uint32_t tile_id = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-contiguous bands
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
     __shared__ float acc_all[DET ? TPB : 1][kBatch][12];  // DET: 9 used; 48-byte rows keep b128 stores aligned
     __shared__ float stage_all[DET ? 1 : TPB][kStageRows * kRowWords];
     constexpr uint32_t kWavesPerTile = 4u / NQ;
+    BRUSH_KTRACE(kTrRasterizeBwd, 0);
 
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     BwdRecs &lds = lds_all[wv];

@@ -10,6 +10,7 @@
 
 #include "internal.hpp"
 #include "splat_math.hpp"
+#include "trace.hpp"
 
 namespace brush {
 
@@ -479,6 +480,40 @@ extern "C" int brush_reduce_view_records_adam(const float *records, uint32_t num
                              nullptr, nullptr,
                              nullptr, nullptr, nullptr, &af, view_index, view_index_bytes, stream);
 }
+
+#ifdef BRUSH_TRACE
+// ---- development build only (make trace): the in-kernel timeline ring of trace.hpp --------------------------
+#include <vector>
+namespace brush {
+static std::vector<void (*)(TraceRec *, uint32_t *)> &trace_attachers() {
+    static std::vector<void (*)(TraceRec *, uint32_t *)> v;
+    return v;
+}
+void trace_register(void (*attach)(TraceRec *, uint32_t *)) { trace_attachers().push_back(attach); }
+static TraceRec *g_trace_ring = nullptr;
+static uint32_t *g_trace_cursor = nullptr;
+}  // namespace brush
+// Allocates the ring on first use, points every translation unit at it and resets the cursor.
+extern "C" int brush_debug_trace_begin(void) {
+    if (!g_trace_ring) {
+        BRUSH_HIP_CHECK(hipMalloc(&g_trace_ring, sizeof(TraceRec) * kTraceCap));
+        BRUSH_HIP_CHECK(hipMalloc(&g_trace_cursor, 256));
+        for (auto f : trace_attachers()) f(g_trace_ring, g_trace_cursor);
+    }
+    BRUSH_HIP_CHECK(hipMemset(g_trace_ring, 0, sizeof(TraceRec) * kTraceCap));
+    BRUSH_HIP_CHECK(hipDeviceSynchronize());
+    return BRUSH_OK;
+}
+// Copies up to max_records 64-byte records to the host; returns how many were written (< 0: error).
+extern "C" long brush_debug_trace_read(void *out, size_t max_records) {
+    if (!g_trace_ring || !out) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    uint32_t n = kTraceCap;  // slots nobody wrote stay zero (t[0] == 0)
+    if (n > max_records) n = (uint32_t)max_records;
+    if (n && hipMemcpy(out, g_trace_ring, sizeof(TraceRec) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -4;
+    return (long)n;
+}
+#endif
 
 // ---- opt-in stage timing ------------------------------------------------------------------
 

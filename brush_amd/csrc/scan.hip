@@ -17,6 +17,7 @@
 // HBM traffic: 8 B/element + a second read of the input that hits the Infinity Cache for the
 // sizes on this path (N*4 B <= 80 MB).  Roofline: HBM.
 #include "common.hpp"
+#include "trace.hpp"
 
 namespace brush {
 namespace {
@@ -44,13 +45,15 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const uint32_t *__
                                                              const uint32_t *__restrict__ d_valid_n,
                                                              uint32_t *__restrict__ tile_sums) {
     __shared__ uint32_t wave_tot[kScanThreads / kWave];
+    BRUSH_KTRACE(kTrScanReduce, 0);
     const uint32_t valid_n = d_valid_n ? min(*d_valid_n, n) : n;
+    BRUSH_KTRACE_MARK(1, valid_n);
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
     const uint32_t idx = blockIdx.x * kScanTile + threadIdx.x * 4;
     const uint4 v = load_tile4(in, idx, n, valid_n, aligned);
     uint32_t s = v.x + v.y + v.z + v.w;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    BRUSH_KTRACE_MARK(2, s);
+    s = wave_sum(s);
     if (lane_id() == 0) wave_tot[threadIdx.x / kWave] = s;
     __syncthreads();
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
@@ -100,17 +103,20 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_down(const uint32_t *__re
                                                            uint32_t *__restrict__ d_overflow) {
     __shared__ uint32_t wave_tot[kScanThreads / kWave];
     __shared__ uint32_t pre_s[kScanThreads / kWave];
+    BRUSH_KTRACE(kTrScanDown, 0);
     if (SELF) {
         uint32_t before = 0;
         for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kScanThreads) before += tile_prefix[i];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+        BRUSH_KTRACE_MARK(1, before);
+        before = wave_sum(before);
         if (lane_id() == 0) pre_s[threadIdx.x / kWave] = before;
     }
     const uint32_t valid_n = d_valid_n ? min(*d_valid_n, n) : n;
     const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
     const uint32_t idx = blockIdx.x * kScanTile + threadIdx.x * 4;
+    BRUSH_KTRACE_MARK(2, valid_n);
     uint4 v = load_tile4(in, idx, n, valid_n, aligned);
+    BRUSH_KTRACE_MARK(3, v.x + v.w);
     v.y += v.x;
     v.z += v.y;
     v.w += v.z;
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_down(const uint32_t *__re
     v.y += off;
     v.z += off;
     v.w += off;
+    BRUSH_KTRACE_MARK(4, v.w);
     if (idx >= n) return;
     if (aligned && idx + 4 <= n) {
         *reinterpret_cast<uint4 *>(out + idx) = v;
