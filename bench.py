@@ -10,9 +10,13 @@ and the step ends with the SUM of the per-view parameter gradients on every rank
 default through an RCCL all-gather of 64-byte per-visible-splat records and a deterministic
 per-splat reduction (brush_amd/dist.py), with --dense-allreduce through one all-reduce of the dense
 block; scaling is weak (per-GPU work fixed).  Rank 0 prints ONE JSON line; `train` in it is the full
-training iteration (loss + Adam) at the same N.  At N=1 the K steps are timed twice after W warm-up steps each, as one
-replayed hipGraph and as eager launches through the C ABI; `value` is the faster of the two (`config.launch` names it,
-`whole_path.graph_ms_per_step` / `.eager_ms_per_step` keep both).
+training iteration (loss + Adam) at the same N.  At N=1 `value` is the K steps replayed as one captured hipGraph after
+W warm-up replays (the launch mode of every earlier round's number); the same K steps as eager launches through the
+C ABI are timed beside it (`whole_path.eager_ms_per_step`).  `stage_ms` are IN-SITU stage times: the captured prefixes
+cull .. stage k of the step are timed as replayed graphs and differenced (brush_profiler_stop_after), so they add up to
+the step; `stage_ms_events` are the hipEvent times of eager passes that earlier rounds reported (every event record adds
+~3-5 us to its stage).  At N>1 the three gradient-exchange forms (records padded / records packed / dense all-reduce)
+are timed in the same run (`exchange_variants`) and `value` is the fastest.
 """
 from __future__ import annotations
 
@@ -30,6 +34,8 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+# the launch-bound middle of the forward + the accumulator zero-fill (VERDICT r03 "seven small stages")
+SMALL_STAGES = ("depth_sort", "project_visible", "prefix_sum", "map_intersects", "tile_sort", "tile_bins", "bwd_zero")
 VALU_PEAK_GINST = 923.9  # wave64 v_fma_f32/s: 256 CUs * 4 SIMDs * 2.4 GHz / 2.66 cycles (measured, tools/ubench)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
@@ -77,6 +83,23 @@ def view_camera(rank, w, h):
     rot = [0.0, math.sin(ang / 2), 0.0, math.cos(ang / 2)]
     pos = [-8.0 * math.sin(ang), 0.0, -8.0 * math.cos(ang)]
     return brush_amd.Camera(pos, rot, fov_x, fov_y, (0.5, 0.5))
+
+
+def kernel_sources_sha16():
+    """Fingerprint of the kernel sources (brush_amd/csrc/*.hip, *.hpp, include/brush_hip.h): profiles/traffic.json
+    carries the one it was taken at (tools/summarize_profiles.py), so a counter figure older than the kernels is
+    reported as stale instead of being passed off as this build's traffic."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "brush_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "brush_amd", "csrc", "*.hpp")) +
+                   [os.path.join(ROOT, "include", "brush_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(n, V, I, P, T, C, fwd_only=False):
@@ -225,41 +248,64 @@ def main():
 
     wl = Workload(p, n, w, h, cam, cap)
     exchange_mode = None
+    exchange_variants = None
     if world == 1:
         if not args.no_graph:
             wl.capture()
         step = wl.step
-    elif args.dense_allreduce:
-        # the north-star's form: dense gradients, one all-reduce of the 52+12C B/splat block (RCCL over xGMI)
-        exchange_mode = "dense all-reduce of the [v_means|v_scales|v_quats|v_opac|v_sh] block"
-        if not args.no_graph:
-            wl.capture()
-
-        def step():
-            aux = wl.step()
-            BD.allreduce_param_grads(wl.block, n, C)
-            return aux
+        elapsed = timed(step, args.steps, args.warmup)
     else:
-        # default: 64-byte records of the visible splats, all-gather, deterministic per-splat sum (brush_amd/dist.py)
-        exchange_mode = ("all-gather of 64-byte per-visible-splat gradient records + deterministic per-splat sum over "
-                         "views into the dense block (same sum on every rank, bit for bit)")
-        xchg = BD.ViewExchange(n, C, dev)
+        # N > 1: one view per rank; the step ends with the SUM of the per-view parameter gradients on every rank.  Three
+        # exchange forms, each W warm-up + K timed steps in this run; `value` is the fastest (the ranking on xGMI is not
+        # known before the first hardware run: DESIGN.md §6).
+        NAMES = {
+            "records_padded": "all-gather (one all_gather_into_tensor, views padded to the largest) of 64-byte "
+                              "per-visible-splat gradient records + deterministic per-splat sum over views into the dense "
+                              "block (same sum on every rank, bit for bit)",
+            "records_packed": "exact-size exchange (one broadcast per view) of the 64-byte records + the same "
+                              "deterministic per-splat sum",
+            "dense_allreduce": "dense all-reduce of the [v_means|v_scales|v_quats|v_opac|v_sh] block (52+12C B/splat)",
+        }
         if not args.no_graph:
             wl.capture_forward()
 
-        def step():
-            if wl.graph_fwd is not None:
-                wl.graph_fwd.replay()
-                out, aux, u = wl.fwd_res
-            else:
-                out, aux, u = wl.forward()
-            xchg.begin(aux)
-            xchg.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, wl.v_out)
-            xchg.gather()
-            xchg.reduce_dense(p["means"], wl.block)
+        def make_records_step(xchg):
+            def record_step():
+                if wl.graph_fwd is not None:
+                    wl.graph_fwd.replay()
+                    out, aux, u = wl.fwd_res
+                else:
+                    out, aux, u = wl.forward()
+                xchg.begin(aux)
+                xchg.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, wl.v_out)
+                xchg.gather()
+                xchg.reduce_dense(p["means"], wl.block)
+                return aux
+            return record_step
+
+        def dense_step():
+            aux = wl.fwd_bwd()  # eager: the forward graph above and a fwd+bwd graph would double the captured pools
+            BD.allreduce_param_grads(wl.block, n, C)
             return aux
 
-    elapsed = timed(step, args.steps, args.warmup)
+        xchgs = {"records_padded": BD.ViewExchange(n, C, dev, packed=False),
+                 "records_packed": BD.ViewExchange(n, C, dev, packed=True)}
+        steps_by_name = {"records_padded": make_records_step(xchgs["records_padded"]),
+                         "records_packed": make_records_step(xchgs["records_packed"]), "dense_allreduce": dense_step}
+        todo = ["dense_allreduce"] if args.dense_allreduce else list(steps_by_name)
+        exchange_variants, best = {}, None
+        for name in todo:
+            sec = timed(steps_by_name[name], args.steps, args.warmup)
+            exchange_variants[name] = {"ms_per_step": round(sec * 1e3 / args.steps, 4),
+                                       "views_per_s": round(n_gpus * args.steps / sec, 3), "what": NAMES[name]}
+            x = xchgs.get(name)
+            if x is not None:  # did the host ever wait for the per-view counts (ViewExchange.counts)?
+                exchange_variants[name]["host_waits"] = x.host_waits
+                exchange_variants[name]["host_wait_ms_per_step"] = round(x.host_wait_s * 1e3 / (args.steps + args.warmup), 4)
+            if best is None or sec < best[1]:
+                best = (name, sec)
+        step, elapsed = steps_by_name[best[0]], best[1]
+        exchange_mode = NAMES[best[0]] + (" — fastest of the forms timed in this run" if len(todo) > 1 else "")
     aux = step()
     torch.cuda.synchronize()
     ms_per_step = elapsed * 1e3 / args.steps
@@ -270,17 +316,13 @@ def main():
     P, T = w * h, (-(-w // 16)) * (-(-h // 16))
 
     # the same fwd+bwd as eager launches (host enqueue cost included), N=1 only: the same K steps after the same W
-    # warm-up steps.  The line reports the faster of the two launch modes (both are complete executions of the step
-    # through the C ABI; `config.launch` says which, `whole_path` keeps both times).
+    # warm-up steps.  `value` stays the graph replay (as in every earlier round); `whole_path` keeps both times.
     eager_ms = graph_ms = None
     launch_used = None
     if world == 1 and wl.graph is not None:
         graph_ms = ms_per_step
         eager_elapsed = timed(wl.fwd_bwd, args.steps, args.warmup)
         eager_ms = eager_elapsed * 1e3 / args.steps
-        if eager_ms < graph_ms:
-            ms_per_step, value = eager_ms, n_gpus * args.steps / eager_elapsed
-            launch_used = "eager launches through the C ABI (hipGraph replay of the same step: %.4f ms)" % graph_ms
 
     # ---- per-stage device time (hipEvents on the op's stream), separate untimed steps ----
     def profile_stages(workload, steps):
@@ -302,35 +344,92 @@ def main():
         ach = nbytes / (st_ms[dom] * 1e-3) / 1e9 if st_ms[dom] > 0 else 0.0
         return dom, nbytes, ach
 
-    stage_ms = profile_stages(wl, args.profile_steps)
-    dominant, dom_bytes, achieved = dominant_roofline(stage_ms, n, V, I, P, T, C)
-    traffic, valu, traffic_src = None, None, None
+    def profile_stages_in_situ(workload, replays=12, rounds=3, copies=4):
+        """Stage times without event overhead: for every stage k the prefix cull .. k of the step is captured as a graph
+        (`copies` back-to-back passes per graph, so a short prefix is not bound by the host's replay rate), replayed,
+        and the prefix times are differenced.  The last prefix is the whole step."""
+        res, prev = {}, 0.0
+        with StageProfiler() as prof:
+            names = prof.names
+            n_fwd = names.index("rasterize") + 1
+            try:
+                for k, name in enumerate(names):
+                    prof.stop_after(name)
+
+                    def fn():
+                        for _ in range(copies):
+                            q = workload.p
+                            out, aux, u = workload.forward()
+                            if k >= n_fwd:
+                                R._backward_impl(u, aux, q["means"], q["log_scales"], q["quats"], q["raw_opac"], workload.C,
+                                                 out, workload.v_out, workload.block)
+
+                    g, _ = workload._capture(fn)
+                    best = None
+                    for _ in range(rounds):
+                        g.replay()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(replays):
+                            g.replay()
+                        torch.cuda.synchronize()
+                        t = (time.perf_counter() - t0) * 1e3 / (replays * copies)
+                        best = t if best is None else min(best, t)
+                    res[name] = max(best - prev, 0.0)
+                    prev = best
+                    del g
+            finally:
+                prof.stop_after(None)
+        torch.cuda.empty_cache()
+        return res, prev
+
+    stage_ms_events = profile_stages(wl, args.profile_steps)
+    stage_ms, prefix_total_ms = (None, None)
+    if world == 1 and args.profile_steps > 0:
+        stage_ms, prefix_total_ms = profile_stages_in_situ(wl)
+    if stage_ms is None:
+        stage_ms = stage_ms_events
+    # the roofline object prices the dominant kernel with its hipEvent time on the op's stream (the contract's clock)
+    dominant, dom_bytes, achieved = dominant_roofline(stage_ms_events, n, V, I, P, T, C)
+    traffic, valu, traffic_src, traffic_stale = None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     tj = {}
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(dominant)
+            fresh = tj.get("_csrc_sha16") == kernel_sources_sha16()
             traffic_src = (f"profiles/traffic.json (tag {tj.get('_tag', 'static')}, taken at commit {tj.get('_commit', '?')}): "
                            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (tools/profile_gpu.sh), not "
-                           "re-measured in this run")
-            insts = tj.get("valu_insts", {}).get(dominant)
-            if insts and stage_ms[dominant] > 0:
+                           "re-measured in this run; " +
+                           ("the kernel sources are the ones the counters were taken on" if fresh else
+                            "STALE: the kernel sources have changed since (fingerprint mismatch), so the figure is "
+                            "reported as traffic_stale and `traffic` is null"))
+            if not fresh:
+                traffic_stale, traffic = traffic, None
+            insts = tj.get("valu_insts", {}).get(dominant) if fresh else None
+            if insts and stage_ms_events[dominant] > 0:
                 # The ceiling that binds the compositing kernels (DESIGN.md §4): VALU issue.  Measured with
                 # tools/ubench/valu_rate.hip: one v_fma_f32 per 2.66 SIMD cycles at 8 waves/SIMD.
-                rate = insts / (stage_ms[dominant] * 1e-3) / 1e9
+                rate = insts / (stage_ms_events[dominant] * 1e-3) / 1e9
                 valu = {"insts_per_launch": int(insts), "achieved_Ginst_s": round(rate, 1), "peak_Ginst_s": VALU_PEAK_GINST,
                         "frac": round(rate / VALU_PEAK_GINST, 4),
                         # every VALU lane-op counted as one FMA (2 flop): an upper bound of the fraction of the
                         # 157.3 TFLOP/s vector peak (SURVEY 8d asks for this figure)
-                        "valu_flops_frac_upper_bound": round(insts * 64 * 2 / (stage_ms[dominant] * 1e-3) / 157.3e12, 4),
+                        "valu_flops_frac_upper_bound": round(insts * 64 * 2 / (stage_ms_events[dominant] * 1e-3) / 157.3e12, 4),
                         "note": "SQ_INSTS_VALU per launch from profiles/ (rocprofv3 --pmc) / live kernel time; peak = "
                                 "1024 SIMDs * 2.4 GHz / 2.66 cycles per v_fma_f32 (measured, profiles/r02a_valu_rate.txt)"}
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(stage_ms[dominant], 5), "valu_issue": valu}
+                "algorithmic_bytes": int(dom_bytes), "kernel_ms": round(stage_ms_events[dominant], 5),
+                "kernel_ms_in_situ": round(stage_ms[dominant], 5), "valu_issue": valu}
+    if traffic is not None and stage_ms_events[dominant] > 0:
+        # what the memory system really moved for this kernel, against the same peak
+        roofline["frac_traffic"] = round(traffic / (stage_ms_events[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    if traffic_stale is not None:
+        roofline["traffic_stale"] = traffic_stale
     # Device-to-device copy bandwidth measured in the same run (SURVEY §8d): 1 GiB read + 1 GiB write.
     src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
     dst = torch.empty_like(src)
@@ -410,6 +509,7 @@ def main():
                 Bx = algorithmic_bytes(c["n"], Vx, Ix, Px, Tx, Cx)
                 st = profile_stages(x, 3)
                 dom, dbytes, ach = dominant_roofline(st, c["n"], Vx, Ix, Px, Tx, Cx)
+                tr = tj.get("extra", {}).get(name, {}).get(dom) if tj.get("_csrc_sha16") == kernel_sources_sha16() else None
                 extra[name] = {"workload": f"{c['n']} splats @{c['w']}x{c['h']}, SH degree {c['deg']}, mean_mult {c['mean_mult']}",
                                "ms_per_step": round(sec * 1e3 / c["steps"], 4), "num_visible": Vx, "num_intersections": Ix,
                                "max_intersects": ax.max_intersects, "overflow": int(ax.overflow.item()),
@@ -419,7 +519,12 @@ def main():
                                "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                                             "algorithmic_bytes": int(dbytes), "kernel_ms": round(st[dom], 5),
-                                            "traffic": tj.get("extra", {}).get(name, {}).get(dom)}}
+                                            "traffic": tr,
+                                            # counter bytes / kernel time: the fraction that means something when the
+                                            # lists are not walked to their end (c3: the saturated frame stops early,
+                                            # the I*76 formula credits bytes that never move)
+                                            "frac_traffic": None if not tr or st[dom] <= 0 else round(
+                                                tr / (st[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
                 del x, pp, ax
                 torch.cuda.empty_cache()
             except Exception as e:  # an extra line must never take the headline down
@@ -446,8 +551,9 @@ def main():
 
     if rank == 0:
         launch = launch_used if launch_used else "eager" if args.no_graph else (
-            "hipGraph replay of one fwd+bwd" if world == 1 or args.dense_allreduce else
-            "hipGraph replay of the forward; backward, all-gather and reduction enqueued per step")
+            "hipGraph replay of one fwd+bwd" if world == 1 else
+            "record forms: hipGraph replay of the forward, then backward, exchange and reduction enqueued per step; dense "
+            "all-reduce form: eager launches")
         line = {
             "metric": "fwd+bwd views/s (train-iter rate of the rasterizer path), 1M splats @1080p",
             "value": round(value, 3), "unit": "views/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -460,7 +566,15 @@ def main():
                        "num_visible": V, "num_intersections": I, "max_intersects": aux.max_intersects,
                        "overflow": overflow},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "whole_path": whole_path, "train": train,
-            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()}, "extra_workloads": extra,
+            "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+            "stage_ms_method": ("in situ: differences of replayed prefix graphs cull..stage (brush_profiler_stop_after); sum = "
+                                f"{sum(stage_ms.values()):.4f} ms vs the step's {ms_per_step:.4f}") if prefix_total_ms else
+                               "hipEvents between the stages of eager passes",
+            "stage_ms_events": {k: round(v, 5) for k, v in stage_ms_events.items()},
+            "small_stages_ms": {"in_situ": round(sum(stage_ms[k] for k in SMALL_STAGES), 5),
+                                "events": round(sum(stage_ms_events[k] for k in SMALL_STAGES), 5),
+                                "stages": list(SMALL_STAGES)},
+            "exchange_variants": exchange_variants, "extra_workloads": extra,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -22,4 +22,4 @@ from .gaussian_splats import Splats  # noqa: F401
 from .train import SplatTrainer, TrainConfig  # noqa: F401
 from . import dataset  # noqa: F401
 
-__version__ = "0.3.0"
+__version__ = "0.4.0"

@@ -125,6 +125,7 @@ _SYMBOLS = [
     ("brush_profiler_destroy", None, [_P]),
     ("brush_profiler_attach", None, [_P]),
     ("brush_profiler_read", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("brush_profiler_stop_after", C.c_int, [_P, C.c_int]),
     ("brush_stage_name", C.c_char_p, [C.c_int]),
 ]
 
@@ -144,6 +145,11 @@ def lib():
             "or `make -C brush_amd/csrc`. brush_amd has no CPU fallback.")
     import torch  # noqa: F401  (loads torch's libamdhip64.so first; same SONAME is then reused)
 
+    if os.environ.get("BRUSH_HIP_LIB"):
+        import warnings
+
+        warnings.warn(f"brush_amd: BRUSH_HIP_LIB is set, loading {LIB_PATH} instead of the product library",
+                      RuntimeWarning, stacklevel=2)
     handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, restype, argtypes in _SYMBOLS:
         fn = getattr(handle, name)  # AttributeError if the header and the library diverge

@@ -889,7 +889,7 @@ hipError_t launch_reduce_view_records(const float *records, uint32_t num_views, 
                                       float *v_quats, float *v_sh, float *v_opac, const AdamFuse *adam, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const float4 *rec4 = reinterpret_cast<const float4 *>(records);
-    if (num_views * rows_per_view > 0)
+    if (num_views > 0 && rows_per_view > 0)  // (a u32 product would wrap to 0 at 8 views x 2^29 rows and skip the index)
         hipLaunchKernelGGL(k_build_view_index, dim3(min(ceil_div(rows_per_view, kThreads), 2048u)), dim3(kThreads), 0, s,
                            rec4, num_views, rows_per_view, view_rows, view_offsets, n, index);
     const dim3 grid(ceil_div(n, kThreads)), block(kThreads);

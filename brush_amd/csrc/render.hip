@@ -27,19 +27,23 @@ struct BrushProfiler {
     hipEvent_t fwd[kFwdStages + 1];
     hipEvent_t bwd[kBwdStages + 1];
     bool fwd_recorded = false, bwd_recorded = false;
+    int stop_after = -1;  // brush_profiler_stop_after: the pass ends behind this stage, no events
 };
 
 namespace brush {
 static thread_local BrushProfiler *g_prof = nullptr;
 
+// true: the attached profiler asks the pass to end behind `stage` (prefix timing)
+static inline bool stop_behind(int stage) { return g_prof && g_prof->stop_after == stage; }
+
 static inline void mark_fwd(hipStream_t s, int idx) {
-    if (g_prof) {
+    if (g_prof && g_prof->stop_after < 0) {
         (void)hipEventRecord(g_prof->fwd[idx], s);
         if (idx == BrushProfiler::kFwdStages) g_prof->fwd_recorded = true;
     }
 }
 static inline void mark_bwd(hipStream_t s, int idx) {
-    if (g_prof) {
+    if (g_prof && g_prof->stop_after < 0) {
         (void)hipEventRecord(g_prof->bwd[idx], s);
         if (idx == BrushProfiler::kBwdStages) g_prof->bwd_recorded = true;
     }
@@ -138,7 +142,10 @@ bool uniforms_ok(const BrushUniforms *u) {
 
 using namespace brush;
 
-extern "C" const char *brush_version(void) { return "brush_amd 0.3.0 (gfx950)"; }
+#ifndef BRUSH_BUILD_TAG
+#define BRUSH_BUILD_TAG ""  // the test / development twins of the library name themselves here (Makefile)
+#endif
+extern "C" const char *brush_version(void) { return "brush_amd 0.4.0 (gfx950)" BRUSH_BUILD_TAG; }
 
 extern "C" const char *brush_status_string(int status) {
     switch (status) {
@@ -221,23 +228,28 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
                                         ws.proj_global, ws.key_all, ws.block_counts, ws.pre_keys, ws.pre_gids,
                                         ws.bin_edges, ws.walk, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_CULL);
+    if (stop_behind(BRUSH_STAGE_PROJECT_CULL)) return BRUSH_OK;
     // DepthSort: keys = f32 depth bits, all 32 bits (render.rs:151-156)
     BRUSH_HIP_CHECK(sort_launch(ws.pre_keys, ws.pre_gids, ws.sorted_keys, aux.global_from_compact_gid,
                                 aux.num_visible, n, 32, ws.sort_ws, s));
     mark_fwd(s, 1 + BRUSH_STAGE_DEPTH_SORT);
+    if (stop_behind(BRUSH_STAGE_DEPTH_SORT)) return BRUSH_OK;
     // ProjectVisible (render.rs:161-184)
     BRUSH_HIP_CHECK(launch_project_visible(vp, ws.proj_global, aux.num_visible, aux.global_from_compact_gid,
                                            aux.compact_from_global_gid, aux.projected_splats, ws.tiles_hit,
                                            ws.walk, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_VISIBLE);
+    if (stop_behind(BRUSH_STAGE_PROJECT_VISIBLE)) return BRUSH_OK;
     // PrefixSum over all N, tail treated as 0 (render.rs:186-192); total -> num_intersections
     BRUSH_HIP_CHECK(scan_launch(ws.tiles_hit, aux.cum_tiles_hit, n, aux.num_visible, aux.num_intersections, cap,
                                 aux.overflow, ws.scan_ws, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PREFIX_SUM);
+    if (stop_behind(BRUSH_STAGE_PREFIX_SUM)) return BRUSH_OK;
     // MapGaussiansToIntersect (render.rs:211-223)
     BRUSH_HIP_CHECK(launch_map_intersects(vp, aux.projected_splats, aux.cum_tiles_hit, aux.num_visible, cap,
                                           ws.tile_unsorted, ws.gid_unsorted, ws.walk, s));
     mark_fwd(s, 1 + BRUSH_STAGE_MAP_INTERSECTS);
+    if (stop_behind(BRUSH_STAGE_MAP_INTERSECTS)) return BRUSH_OK;
     // Tile sort on bits = 32 - clz(num_tiles) (render.rs:227-237)
     uint32_t bits = 0;
     while (bits < 32 && (num_tiles >> bits) != 0) bits++;
@@ -254,10 +266,12 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
                                 det ? aux.isect_unsorted_pos : aux.compact_gid_from_isect, aux.num_intersections, cap,
                                 bits, ws.sort_ws, s, det ? nullptr : ws.bin_edges, num_tiles));
     mark_fwd(s, 1 + BRUSH_STAGE_TILE_SORT);
+    if (stop_behind(BRUSH_STAGE_TILE_SORT)) return BRUSH_OK;
     if (det)
         BRUSH_HIP_CHECK(launch_tile_bin_edges(ws.tile_sorted, aux.num_intersections, cap, aux.tile_bins,
                                               aux.isect_unsorted_pos, ws.gid_unsorted, aux.compact_gid_from_isect, s));
     mark_fwd(s, 1 + BRUSH_STAGE_TILE_BINS);
+    if (stop_behind(BRUSH_STAGE_TILE_BINS)) return BRUSH_OK;
     // Rasterize (render.rs:267-307)
     BRUSH_HIP_CHECK(launch_rasterize(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
                                      det ? nullptr : ws.bin_edges, aux.projected_splats, raster_u32,
@@ -309,6 +323,7 @@ static int composite_backward(const BrushUniforms &u, const BrushAux &aux, const
     // compact-order accumulators are atomically added to: zero the first V rows (render.rs:505-507)
     BRUSH_HIP_CHECK(launch_zero_compact_grads(aux.num_visible, n, ws.v_compact, s));
     mark_bwd(s, 1);
+    if (stop_behind(BRUSH_STAGE_BWD_ZERO)) return BRUSH_OK;
     BRUSH_HIP_CHECK(launch_rasterize_backward(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
                                               aux.projected_splats, aux.final_index, out_img, v_out, ws.v_compact,
                                               nullptr, nullptr, s));
@@ -337,6 +352,7 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
     mark_bwd(s, 0);
     DetSumsArgs det;
     if (const int rc = composite_backward(u, aux, out_img, v_out, n, ws, &det, s)) return rc;
+    if (stop_behind(BRUSH_STAGE_BWD_ZERO) || stop_behind(BRUSH_STAGE_RASTERIZE_BWD)) return BRUSH_OK;
     // GatherGrads + ProjectBackwards fused, dense outputs written once (render.rs:534-594)
     BRUSH_HIP_CHECK(launch_project_backward(vp, means, log_scales, quats, raw_opacity, aux.compact_from_global_gid,
                                             ws.v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac, adam, det,
@@ -549,6 +565,12 @@ extern "C" int brush_profiler_read(BrushProfiler *p, float *h_ms) {
         for (int i = 0; i < BrushProfiler::kBwdStages; i++)
             BRUSH_HIP_CHECK(hipEventElapsedTime(&h_ms[BrushProfiler::kFwdStages + i], p->bwd[i], p->bwd[i + 1]));
     }
+    return BRUSH_OK;
+}
+
+extern "C" int brush_profiler_stop_after(BrushProfiler *p, int stage) {
+    if (!p || stage < -1 || stage >= BRUSH_NUM_STAGES) return BRUSH_ERR_INVALID_ARG;
+    p->stop_after = stage;
     return BRUSH_OK;
 }
 

@@ -176,11 +176,16 @@ class ViewExchange:
         grads = xchg.reduce_dense(means)   or   xchg.reduce_adam(cfg, params..., moments...)
     """
 
-    def __init__(self, n: int, ncoef: int, device, group: Optional[dist.ProcessGroup] = None, packed: bool = True):
+    def __init__(self, n: int, ncoef: int, device, group: Optional[dist.ProcessGroup] = None, packed: bool = False):
         self.n, self.ncoef, self.device, self.group = int(n), int(ncoef), torch.device(device), group
-        # packed: the all-gather moves exactly num_visible records per view (sum over views) and the reduction reads
-        # them through per-view row offsets; False: every view padded to the largest (W x max), one plain all_gather
+        # packed=False (default): every view padded to the largest (W x max rows), ONE equal-size
+        # all_gather_into_tensor — the native RCCL collective.  packed=True: exactly num_visible records per view
+        # (sum over views, ~2 % fewer bytes at 8 views) moved by one broadcast per view into a flat buffer that the
+        # reduction reads through per-view row offsets; the same code path on every backend, so what the gloo tests pin is
+        # what RCCL runs.  Neither form has run on RCCL hardware yet (DESIGN.md §6): bench.py --gpus N times both.
         self.packed = bool(packed)
+        self.host_wait_s = 0.0     # time the host spent waiting for the per-view counts (counts())
+        self.host_waits = 0        # ... and how often the counts were not there yet when asked for
         self._offsets_dev = None
         self._offsets_pinned = None
         self.degree = int(round(ncoef ** 0.5)) - 1
@@ -219,7 +224,13 @@ class ViewExchange:
         """Per-view visible counts on the host (waits for the copy `begin` started; normally long finished)."""
         if self._counts_host is None:
             if self.device.type == "cuda":
-                self._event.synchronize()
+                if not self._event.query():  # forward + count all-gather still running: wait, and account for it
+                    import time
+
+                    t0 = time.perf_counter()
+                    self._event.synchronize()
+                    self.host_wait_s += time.perf_counter() - t0
+                    self.host_waits += 1
                 self._counts_host = [int(x) for x in self._host.tolist()]
             else:
                 self._counts_host = [int(x) for x in self.metas[:, 0].tolist()]
@@ -269,8 +280,9 @@ class ViewExchange:
 
     # -- exchange ------------------------------------------------------------------------------
     def _gather_packed(self, counts):
-        """Exact sizes: view v's count[v] records land at row offset sum(count[:v]) of the flat buffer.  RCCL takes the
-        uneven all_gather as grouped broadcasts; gloo (CPU rehearsal) gets one broadcast per view."""
+        """Exact sizes: view v's count[v] records land at row offset sum(count[:v]) of the flat buffer, one broadcast
+        per view on every backend (torch lowers an uneven all_gather on NCCL/RCCL to the same W broadcasts; issuing them
+        here keeps one code path that the gloo tests exercise)."""
         offs = [0]
         for c in counts[:-1]:
             offs.append(offs[-1] + int(c))
@@ -279,15 +291,11 @@ class ViewExchange:
         slices = [flat[offs[r] * _REC:(offs[r] + int(counts[r])) * _REC] for r in range(self.world)]
         mine = self.local[:int(counts[self.rank])].reshape(-1)
         if self.world > 1:
-            backend = dist.get_backend(self.group)
-            if backend == "nccl" and all(int(c) > 0 for c in counts):
-                dist.all_gather(slices, mine, group=self.group)
-            else:
-                slices[self.rank].copy_(mine)
-                for r in range(self.world):
-                    if int(counts[r]) > 0:
-                        dist.broadcast(slices[r], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
-                                       group=self.group)
+            slices[self.rank].copy_(mine)
+            for r in range(self.world):
+                if int(counts[r]) > 0:
+                    dist.broadcast(slices[r], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                   group=self.group)
         else:
             slices[0].copy_(mine)
         if self.device.type == "cuda":

@@ -32,6 +32,12 @@ class StageProfiler:
         _lib.check(self._l.brush_profiler_read(self._h, buf), "brush_profiler_read")
         return {n: float(buf[i]) for i, n in enumerate(self.names)}
 
+    def stop_after(self, stage) -> None:
+        """Measurement only: while attached, forward / backward end behind `stage` (name or index; None = whole pass)
+        and record no events (brush_profiler_stop_after)."""
+        idx = -1 if stage is None else (self.names.index(stage) if isinstance(stage, str) else int(stage))
+        _lib.check(self._l.brush_profiler_stop_after(self._h, idx), "brush_profiler_stop_after")
+
     def close(self):
         if self._h:
             self._l.brush_profiler_destroy(self._h)

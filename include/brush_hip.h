@@ -322,6 +322,12 @@ void brush_profiler_attach(BrushProfiler *p);
 /* Blocks until the recorded events have completed, then writes the milliseconds spent in each
  * stage of the LAST forward and LAST backward call recorded (0 for stages not recorded). */
 int brush_profiler_read(BrushProfiler *p, float *h_ms /* [BRUSH_NUM_STAGES] */);
+/* Measurement only: while `p` is attached, brush_render_forward* / brush_render_backward* return BRUSH_OK right after
+ * the launches of `stage` have been enqueued (later stages are not launched and their outputs stay untouched) and
+ * record no events; stage = -1 restores the whole pass.  Timing the captured prefixes 0..k of a step and taking
+ * differences gives every stage's time IN SITU, without the ~3-5 us an event record adds to each stage of an eager
+ * pass (bench.py: `stage_ms`; the event times stay available as `stage_ms_events`). */
+int brush_profiler_stop_after(BrushProfiler *p, int stage);
 const char *brush_stage_name(int stage);
 
 #ifdef __cplusplus

@@ -59,7 +59,7 @@ def _inverse_map(aux_np, n):
     return torch.from_numpy(inv)
 
 
-def _worker(rank, world, port, n, w, h, deg, q):
+def _worker(rank, world, port, n, w, h, deg, packed, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
@@ -85,7 +85,7 @@ def _worker(rank, world, port, n, w, h, deg, q):
         ub = torch.zeros(28, dtype=torch.int32)
         ub[:16] = torch.from_numpy(_view_uniforms(rank, w, h, deg)["viewmat"].view(np.int32).copy())
         aux.uniforms_buffer = ub
-        xchg = BD.ViewExchange(n, ncoef, torch.device("cpu"))
+        xchg = BD.ViewExchange(n, ncoef, torch.device("cpu"), packed=packed)
         xchg.begin(aux)
         rows = -(-max(xchg.counts()) // 256) * 256
         dense = {k: torch.from_numpy(g[k]) for k in ("v_means", "v_scales", "v_quats", "v_opac", "v_sh", "v_xy")}
@@ -103,7 +103,8 @@ def _worker(rank, world, port, n, w, h, deg, q):
 
 
 @pytest.mark.timeout(300)
-def test_view_sharded_allreduce_gloo_world2():
+@pytest.mark.parametrize("packed", [False, True])
+def test_view_sharded_allreduce_gloo_world2(packed):
     from brush_amd import dist as BD
     from brush_amd.render import grad_block_layout
 
@@ -111,7 +112,7 @@ def test_view_sharded_allreduce_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, w, h, deg, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, w, h, deg, packed, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}

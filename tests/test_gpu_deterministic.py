@@ -102,7 +102,7 @@ def test_gradients_are_bitwise_reproducible_and_modes_coexist(dev):
     assert rc == -1  # BRUSH_ERR_INVALID_ARG
 
     # the record form (multi-GPU path) consumes the same sums
-    x = BD.ViewExchange(n, C, dev)
+    x = BD.ViewExchange(n, C, dev, packed=True)
     x.begin(aux)
     x.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, v_out)
     r1 = x.gather()[0].clone()

@@ -67,8 +67,8 @@ def _worker(rank, world, port, q):
             got = red[:pf].detach().cpu()
             # the HIP record kernel against the torch restatement fed with the HIP dense gradients
             V = aux.read_num_visible()
-            mine = recs[rank]  # packed form: exactly V rows of this view, at row offset sum of the counts before it
-            assert mine.shape[0] == V and sum(r.shape[0] for r in recs) == sum(xchg.counts())
+            mine = recs[rank]  # default (padded) form: [W, rows, 16], the first V rows of a view are its records
+            assert mine.shape[0] >= V and recs.shape[0] == world and not xchg.packed
             want_rec = BD.records_from_dense_torch(g, aux, n, (w, h), V)
             rec_err = float((mine[:V, 1:].double() - want_rec[:V, 1:].double()).abs().max()
                             / (want_rec[:V, 1:].abs().max() + 1e-30))
@@ -168,7 +168,7 @@ def _refine_worker(rank, world, port, q):
         # refinement every 3 steps with a threshold low enough that it clones / splits / prunes at once
         cfg = brush_amd.TrainConfig(warmup_steps=0, refine_every=3, densify_grad_thresh=1e-7, max_refine_step=100)
         trainer = brush_amd.SplatTrainer(splats, cfg)
-        xchg = BD.ViewExchange(n, ncoef, dev)
+        xchg = BD.ViewExchange(n, ncoef, dev, packed=True)  # the exact-size form (one broadcast per view)
         counts, refines = [], []
         for _ in range(8):
             trainer.step(splats, cam, gt, 1.0, world, None, xchg)

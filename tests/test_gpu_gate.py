@@ -17,7 +17,7 @@ from tests import margins as M
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-INJECT = os.path.join(ROOT, "brush_amd", "lib", "libbrush_hip_inject.so")
+INJECT = os.path.join(ROOT, "brush_amd", "csrc", "build", "libbrush_hip_inject.so")
 
 
 @pytest.mark.timeout(900)

@@ -776,7 +776,7 @@ def test_view_records_round_trip(dev, deg):
     v_out = torch.randn((h, w, 4), device=dev) / (h * w)
     g, block = R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], C, out, v_out)
     V = aux.read_num_visible()
-    xchg = BD.ViewExchange(n, C, dev)
+    xchg = BD.ViewExchange(n, C, dev, packed=True)
     xchg.begin(aux)
     xchg.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, v_out)
     recs = xchg.gather()  # packed form: a list with one [V, 16] view of the flat buffer per view
@@ -837,7 +837,7 @@ def test_view_records_many_views(dev, packed):
         cam = brush_amd.Camera(pos, rot, base["fov_x"], base["fov_y"], base["center_uv"])
         out, aux, u = R._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"], False,
                                       2_000_000)
-        x = BD.ViewExchange(n, C, dev)
+        x = BD.ViewExchange(n, C, dev, packed=True)
         x.begin(aux)
         x.backward_records(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], out, v_out)
         recs = x.gather()

@@ -3,7 +3,7 @@ libbrush_hip_trace.so, built with BRUSH_BWD_TRACE)."""
 import ctypes, math, sys, os, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["BRUSH_HIP_LIB"] = os.path.join(ROOT, "brush_amd", "lib", "libbrush_hip_trace.so")
+os.environ["BRUSH_HIP_LIB"] = os.path.join(ROOT, "brush_amd", "csrc", "build", "libbrush_hip_trace.so")
 import numpy as np
 import torch
 import brush_amd

@@ -80,6 +80,21 @@ STAGES = {"project_cull": ["k_project_cull", "k_cull_scan", "k_compact"], "proje
           "sort": ["k_sort_upsweep", "k_sort_scan", "k_sort_downsweep"]}
 traffic["valu_insts"] = {}
 traffic["_tag"] = tag
+
+
+def kernel_sources_sha16():
+    """Same fingerprint as bench.py's: bench.py reports these counters as stale once the kernel sources differ."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob("brush_amd/csrc/*.hip") + glob.glob("brush_amd/csrc/*.hpp") + ["include/brush_hip.h"])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+traffic["_csrc_sha16"] = kernel_sources_sha16()
 try:  # the bench line quotes this: which commit the counters were taken at
     import subprocess
     traffic["_commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
