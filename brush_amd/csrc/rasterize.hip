@@ -265,25 +265,10 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     return v;
 }
 
-#ifdef BRUSH_BWD_TRACE  // development build (make trace): per-wave timeline of the compositing backward, read by
-// tools/debug/bwd_timeline.py through brush_debug_read_bwd_trace
-__device__ uint64_t g_bwd_trace[16384 * 4];
-struct BwdTrace {
-    uint64_t t0;
-    uint32_t wid, recs;
-    __device__ ~BwdTrace() {
-        if (lane_id() == 0 && wid < 16384u) {
-            uint32_t hwid, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            g_bwd_trace[wid * 4 + 0] = t0;
-            g_bwd_trace[wid * 4 + 1] = (uint64_t)wall_clock64();
-            g_bwd_trace[wid * 4 + 2] = ((uint64_t)xcc << 32) | hwid;
-            g_bwd_trace[wid * 4 + 3] = ((uint64_t)1 << 48) | ((uint64_t)recs << 24);
-        }
-    }
-};
-#endif
+// development / test-only hooks (identity in the product build): dev_vva, dev_flush, dev_skip_reduce, BRUSH_DEV_BWD_TRACE
+#define BRUSH_DEV_SECTION 1
+#include "rasterize_dev.inc"
+
 // Staged records of the backward, one array per field (the forward's QuadRec pads the opacity to 16 bytes).
 struct BwdRecs {
     float4 a[kBatch];    // mean.x, mean.y, conic.x, conic.y
@@ -340,9 +325,7 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
     const uint32_t tile_id = unit / kWavesPerTile, sub = unit % kWavesPerTile;
     if (tile_id >= num_tiles) return;
     const uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
-#ifdef BRUSH_BWD_TRACE
-    const BwdTrace trace{(uint64_t)wall_clock64(), blockIdx.x * TPB + wv, r1 > r0 ? r1 - r0 : 0u};
-#endif
+    BRUSH_DEV_BWD_TRACE(blockIdx.x * TPB + wv, r1 > r0 ? r1 - r0 : 0u);
     if (r1 <= r0) return;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t tx0 = (tile_id % tbx) * kTileWidth, ty0 = (tile_id / tbx) * kTileWidth;
@@ -463,12 +446,7 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
                 // S4 / 2), v_rgb, v_opac = S8
                 const float nopac = -lds.opac[t];
                 const float scale = k >= 5u ? 1.0f : ((k == 2u || k == 4u) ? 0.5f * nopac : nopac);
-                const float val = sum * scale;
-#ifdef BRUSH_ELIM_NO_ATOMICS  // elimination timing (profiles/): everything but the atomic itself
-                if (val == 12345.678f) v_compact[(size_t)lds_gid[t] * kCompactStride + k] = val;
-#else
-                if (val != 0.0f) unsafeAtomicAdd(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], val);
-#endif
+                dev_flush(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], sum * scale);  // != 0: one float atomic
             }
         };
         // One record: its LDS row is read one record AHEAD (software pipeline, two register sets in turn), so the
@@ -517,11 +495,7 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
                     // in gx / gy, the 1/2 of the conic terms) are applied once per record at the flush:
                     //   g0 = sum vva dx, g1 = sum vva dy (default mode: vva gx, vva gy), g2..4 = sum vva (dx dx, dx dy,
                     //   dy dy), g8 = sum vva
-#ifdef BRUSH_INJECT_VVA_ULPS  // test-only build (libbrush_hip_inject.so): a one-signed error of that many eps32 per term
-                    const float vva = fmaf(fabsf(vis * v_alpha), BRUSH_INJECT_VVA_ULPS * 5.9604645e-8f, vis * v_alpha);
-#else
-                    const float vva = vis * v_alpha;
-#endif
+                    const float vva = dev_vva(vis, v_alpha);  // vis * v_alpha
                     const float wx = vva * dx, wy = vva * dy;
                     if (DET) {
                         g[0] += wx;
@@ -541,12 +515,7 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
                 }
             }
             if (ballot64(contributed) != 0ull) {  // wave-uniform: all 64 lanes take part in the reduction
-#ifdef BRUSH_ELIM_NO_REDUCE  // elimination timing (profiles/): no staging, no reduction, no flush
-                if (!DET) {
-                    if (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7] + g[8] == 12345.678f) v_compact[lane] = g[0];
-                    return;
-                }
-#endif
+                if (dev_skip_reduce<DET>(g, v_compact, lane)) return;  // never in the product build
                 if constexpr (!DET) {
                     // park the lane partials as 9 rows of the stage: plain LDS stores, no cross-lane VALU work
                     float *dst = stage + staged * (kGradComps * kRowWords) + lane;
@@ -596,7 +565,7 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
             continue;
         }
         wave_sync();
-        // DET: flush the batch's rows.
+        // DET only from here: flush the batch's rows.
         // acc holds the raw pixel sums; the per-record factors (rasterize_backwards.wgsl:256-263):
         //   v_xy = -opac (a S0 + b S1, b S0 + c S1), v_conic = -opac (S2 / 2, S3, S4 / 2), v_rgb, v_opac = S8
         auto finish = [&](uint32_t t, uint32_t k) -> float {
@@ -608,26 +577,16 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
             const float other = acc[t][k ^ 1u];
             return nopac * (k == 0u ? fmaf(a.z, v, a.w * other) : fmaf(lds.b[t].x, v, a.w * other));
         };
-        if (DET) {
-            // one row per intersection of the batch (zeros where nothing contributed), 12 consecutive lanes per row
-            for (uint32_t f = lane; f < remaining * kCompactStride; f += kWave) {
-                const uint32_t t = f / kCompactStride, k = f - t * kCompactStride;
-                float v = 0.0f;
-                if (k < kGradComps) {
-                    if ((flush_mask >> t) & 1ull) v = finish(t, k);
-                } else if (k == kGradComps) {
-                    v = __uint_as_float(lds_gid[t]);
-                }
-                rows[(size_t)lds_pos[t] * kCompactStride + k] = v;
+        // one row per intersection of the batch (zeros where nothing contributed), 16 consecutive lanes per row
+        for (uint32_t f = lane; f < remaining * kCompactStride; f += kWave) {
+            const uint32_t t = f / kCompactStride, k = f - t * kCompactStride;
+            float v = 0.0f;
+            if (k < kGradComps) {
+                if ((flush_mask >> t) & 1ull) v = finish(t, k);
+            } else if (k == kGradComps) {
+                v = __uint_as_float(lds_gid[t]);
             }
-        } else {
-            for (uint32_t f = lane; f < remaining * kGradComps; f += kWave) {
-                const uint32_t t = f / kGradComps, k = f - t * kGradComps;
-                if ((flush_mask >> t) & 1ull) {
-                    const float v = finish(t, k);
-                    if (v != 0.0f) unsafeAtomicAdd(&v_compact[(size_t)lds_gid[t] * kCompactStride + k], v);
-                }
-            }
+            rows[(size_t)lds_pos[t] * kCompactStride + k] = v;
         }
         batch_end -= remaining;
     }
@@ -728,8 +687,5 @@ hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint3
 
 }  // namespace brush
 
-#ifdef BRUSH_BWD_TRACE
-extern "C" int brush_debug_read_bwd_trace(uint64_t *out, size_t words) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(brush::g_bwd_trace), words * 8);
-}
-#endif
+#define BRUSH_DEV_SECTION 2
+#include "rasterize_dev.inc"

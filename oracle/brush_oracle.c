@@ -305,6 +305,23 @@ static void sh_basis(uint32_t degree, const float *d, float *Y) {
     Y[24] = fTmp3A * fC3;
 }
 
+/* gather_grads.wgsl:186-222: the basis values Y_k(dir) a splat's v_coeffs rows are built from (v_sh[k] = Y_k * v_rgb),
+ * dir = normalize(mean - viewmat[3].xyz) as the shader takes it.  Y is [n][(degree + 1)^2]. */
+int oracle_sh_basis_for_means(const OracleUniforms *u, const float *means, uint32_t n, float *Y_out) {
+    const uint32_t ncoef = (u->sh_degree + 1) * (u->sh_degree + 1);
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < (int64_t)n; g++) {
+        const float *mean = means + (size_t)g * 3;
+        float dir[3] = {mean[0] - u->viewmat[12], mean[1] - u->viewmat[13], mean[2] - u->viewmat[14]};
+        float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        dir[0] = dir[0] / len; dir[1] = dir[1] / len; dir[2] = dir[2] / len;
+        float Y[25];
+        sh_basis(u->sh_degree, dir, Y);
+        for (uint32_t k = 0; k < ncoef; k++) Y_out[(size_t)g * ncoef + k] = Y[k];
+    }
+    return 0;
+}
+
 /* project_visible.wgsl:51-147: colour = sum over bands, each band summed left to right and
  * then added to the running colour, exactly as the WGSL expression tree. */
 static void sh_to_color(uint32_t degree, const float *dir, const float *sh /*[C][3]*/, float *rgb) {

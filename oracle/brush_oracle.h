@@ -113,13 +113,17 @@ int oracle_render_backward_f64(const OracleUniforms *u, const OracleAux *aux, co
                                double *dep_means, double *dep_xy, double *dep_scales, double *dep_quats,
                                double *dep_sh, double *dep_opac,
                                /* rounding magnitude of the SH basis / of the saturating sigmoid */
-                               double *vjp_sh, double *vjp_opac);
+                               double *vjp_sh, double *vjp_opac,
+                               /* optional [h,w,4]: the image of the forward state final_index_alt belongs to */
+                               const float *out_img_alt);
 
 /* Deterministic elementary functions (oracle/detmath.h), exported for tests. */
 float oracle_det_expf(float x);
 float oracle_det_logf(float x);
 
 int oracle_num_threads(void);
+/* Y_k(dir) of gather_grads.wgsl:186-222 for n means: Y_out[n][(sh_degree + 1)^2] */
+int oracle_sh_basis_for_means(const OracleUniforms *u, const float *means, uint32_t n, float *Y_out);
 
 #ifdef __cplusplus
 }

@@ -172,7 +172,8 @@ static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
                                       double *rows_flip /* [I][9] what flipped threshold decisions can move */,
                                       double *rows_dep /* [I][9] sums of |terms| x (divisions T went through) */,
                                       const double *pix_weight /* optional [h,w], see oracle_render_backward_f64 */,
-                                      const uint32_t *final_index_alt /* optional [h,w], likewise */) {
+                                      const uint32_t *final_index_alt /* optional [h,w], likewise */,
+                                      const float *out_img_alt /* optional [h,w,4], likewise */) {
     uint32_t w = u->img_size[0], h = u->img_size[1], tbx = u->tile_bounds[0];
     uint32_t tile_x = tile_id % tbx, tile_y = tile_id / tbx;
     uint32_t r0 = tile_bins[tile_id * 2], r1 = tile_bins[tile_id * 2 + 1];
@@ -183,6 +184,19 @@ static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
     uint8_t inside[TILE_SIZE];
     /* relative change of T at pixel l if the threshold decisions met so far on it went the other way */
     double flip_w[TILE_SIZE], pix_w[TILE_SIZE];
+    /* Stop mismatch (final_index_alt): the entries between the two stops are walked by ONE of the two backwards.  They
+     * leave T of the entries walked later unchanged (each run divides back exactly the factors its own forward
+     * multiplied in), but that run's colour accumulator carries their contributions and its T_final their factors:
+     * dbuf = sum |rgb_k| alpha_k T_k per channel, dtfin = relative change of T_final.  Round 3 priced these entries as
+     * a RELATIVE change alpha/(1 - alpha) of every later term, i.e. in units of the later entry's OWN colour: short
+     * wherever the skipped entries are brighter than the entry under test (1.53x on the 556-entry lists of c5). */
+    double dbuf[TILE_SIZE][3], dtfin[TILE_SIZE];
+    /* ... and each run's T at the LAST COMMON entry is its own forward's (the two forwards reach that entry with
+     * transmittances that differ by their accumulated rounding, ~1e-5 relative after hundreds of factors near the
+     * 1e-4 stop): recovered here as T_final x prod 1/(1 - alpha) over the entries in between and priced like pix_weight
+     * (3 |dT| / min T on every later term of the pixel) once the walk reaches the common part. */
+    double tprod[TILE_SIZE], t_alt[TILE_SIZE];
+    uint8_t mismatch_open[TILE_SIZE];
     double ntaken[TILE_SIZE]; /* roundings (in eps) the recovered T of pixel l has gone through so far */
     for (uint32_t l = 0; l < TILE_SIZE; l++) {
         uint32_t px = tile_x * TILE_WIDTH + l % TILE_WIDTH, py = tile_y * TILE_WIDTH + l / TILE_WIDTH;
@@ -191,6 +205,8 @@ static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
         flip_w[l] = 0.0;
         pix_w[l] = 0.0;
         ntaken[l] = 0.0;
+        dbuf[l][0] = dbuf[l][1] = dbuf[l][2] = dtfin[l] = 0.0;
+        tprod[l] = 1.0; t_alt[l] = 0.0; mismatch_open[l] = 0;
         buf[l][0] = buf[l][1] = buf[l][2] = 0.0;
         fin[l] = fin_lo[l] = fin_hi[l] = 0; T[l] = T_final[l] = 1.0;
         vo[l][0] = vo[l][1] = vo[l][2] = vo[l][3] = 0.0;
@@ -205,6 +221,10 @@ static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
                 fin_hi[l] = alt > fin[l] ? alt : fin[l];
             }
             if (pix_weight) pix_w[l] = pix_weight[pix];
+            if (final_index_alt && out_img_alt && fin_lo[l] != fin_hi[l]) {
+                mismatch_open[l] = 1;
+                t_alt[l] = 1.0 - (double)out_img_alt[pix * 4 + 3];
+            }
             for (int k = 0; k < 4; k++) vo[l][k] = (double)v_out[pix * 4 + k];
         }
     }
@@ -230,7 +250,8 @@ static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
                         (fabsf(fsigma) <= dsig && p[8] >= 1.0f / 255.0f);
             /* an entry only ONE of the two forward states walks (the saturation stop of rasterize.wgsl:88-91 fell on a
              * different entry): present in one backward, absent from the other */
-            if (i > fin_lo[l] && fsigma >= 0.0f && falpha >= 1.0f / 255.0f) risky = 1;
+            const int between = i > fin_lo[l] && fsigma >= 0.0f && falpha >= 1.0f / 255.0f;
+            if (between) risky = 1;
             if (!take && !risky) continue;
             /* values: f64 */
             double dx = (double)p[0] - (double)pcx[l], dy = (double)p[1] - (double)pcy[l];
@@ -241,6 +262,13 @@ static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
             double ra = 1.0 / (1.0 - alpha);
             double Tn = T[l] * ra;
             double fac = alpha * Tn;
+            if (mismatch_open[l] && take && !between) {
+                /* first entry both runs walk: T after it in this run vs in the other one */
+                double t_here = T[l], t_other = (fin[l] == fin_hi[l]) ? t_alt[l] : t_alt[l] * tprod[l];
+                double lo_t = fmin(t_here, t_other);
+                if (lo_t > 0.0) pix_w[l] += 3.0 * fabs(t_here - t_other) / lo_t;
+                mismatch_open[l] = 0;
+            }
             double v_alpha = (p[5] * Tn - buf[l][0] * ra) * vo[l][0] + (p[6] * Tn - buf[l][1] * ra) * vo[l][1] +
                              (p[7] * Tn - buf[l][2] * ra) * vo[l][2] + T_final[l] * ra * vo[l][3];
             double v_sigma = -opac * vis * v_alpha;
@@ -276,7 +304,29 @@ static void d_rasterize_backward_tile(const OracleUniforms *u, uint32_t tile_id,
             double wgt = (risky ? 1.0 : 0.0) + (take ? flip_w[l] + pix_w[l] : 0.0);
             if (wgt > 0.0)
                 for (int k = 0; k < 9; k++) sf[k] += wgt * ma[k];
-            if (risky) flip_w[l] += alpha * ra * 1.05; /* T of the later-walked entries changes by 1/(1 - alpha) */
+            if (take && !between && (dtfin[l] > 0.0 || dbuf[l][0] + dbuf[l][1] + dbuf[l][2] > 0.0)) {
+                /* an entry both runs walk, behind a stop mismatch: v_alpha of the other run differs by the skipped
+                 * entries' colour in buf and by their factors in T_final (rasterize_backwards.wgsl:229-246) */
+                double d_alpha = (dbuf[l][0] * fabs(vo[l][0]) + dbuf[l][1] * fabs(vo[l][1]) + dbuf[l][2] * fabs(vo[l][2])) * ra +
+                                 fabs(T_final[l] * ra * vo[l][3]) * dtfin[l];
+                double d_sigma = opac * vis * d_alpha;
+                sf[0] += d_sigma * (fabs(a * dx) + fabs(b * dy));
+                sf[1] += d_sigma * (fabs(b * dx) + fabs(c * dy));
+                sf[2] += 0.5 * d_sigma * dx * dx;
+                sf[3] += d_sigma * fabs(dx * dy);
+                sf[4] += 0.5 * d_sigma * dy * dy;
+                sf[8] += vis * d_alpha;
+            }
+            if (between) {
+                /* T before this entry in the run that walks it: T[l] here if that run is this one (take), at most
+                 * T_final (of the run that stopped earlier) otherwise */
+                double fk = alpha * (take ? Tn : T_final[l] * ra) * 1.05;
+                dbuf[l][0] += fabs(p[5]) * fk; dbuf[l][1] += fabs(p[6]) * fk; dbuf[l][2] += fabs(p[7]) * fk;
+                dtfin[l] += alpha * ra * 1.05;
+                tprod[l] *= ra;
+            } else if (risky) {
+                flip_w[l] += alpha * ra * 1.05; /* T of the later-walked entries changes by 1/(1 - alpha) */
+            }
         }
         for (int k = 0; k < 9; k++) rows[(size_t)i * 9 + k] = s[k];
         for (int k = 0; k < 9; k++) rows_abs[(size_t)i * 9 + k] = sa[k];
@@ -448,7 +498,9 @@ static void d_project_backward_mag(const OracleUniforms *u, const float *fmean, 
  *   flip_*.  Used when the gradients under test come from a DIFFERENT forward state than the one passed here.
  * final_index_alt (optional, [h,w]): that other forward state's final_index.  Where the two differ (the saturation
  *   stop `T (1 - alpha) <= 1e-4`, rasterize.wgsl:88-91, fell on a different entry) the entries between them exist in
- *   one backward only: their own terms go to flip_* in full, and the pixel's other terms get alpha / (1 - alpha). */
+ *   one backward only: their own terms go to flip_* in full; the entries both runs walk get the skipped entries'
+ *   colour in the accumulator and their factors in T_final (dbuf / dtfin), and — with out_img_alt, the other state's
+ *   image — the difference of the two runs' recovered T at the last common entry. */
 int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux, const float *means,
                                const float *log_scales, const float *quats, const float *raw_opac, uint32_t n,
                                const float *out_img, const float *v_out, double *v_means, double *v_xy,
@@ -458,7 +510,8 @@ int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux,
                                double *flip_quats, double *flip_sh, double *flip_opac, double *vjp_means,
                                double *vjp_scales, double *vjp_quats, const double *pix_weight,
                                const uint32_t *final_index_alt, double *dep_means, double *dep_xy, double *dep_scales,
-                               double *dep_quats, double *dep_sh, double *dep_opac, double *vjp_sh, double *vjp_opac) {
+                               double *dep_quats, double *dep_sh, double *dep_opac, double *vjp_sh, double *vjp_opac,
+                               const float *out_img_alt) {
     OracleUniforms uu = *u_in;
     uu.total_splats = n;
     const OracleUniforms *u = &uu;
@@ -477,7 +530,7 @@ int oracle_render_backward_f64(const OracleUniforms *u_in, const OracleAux *aux,
     for (int64_t t = 0; t < (int64_t)num_tiles; t++)
         d_rasterize_backward_tile(u, (uint32_t)t, aux->compact_gid_from_isect, aux->tile_bins, aux->projected_splats,
                                   aux->final_index, out_img, v_out, rows, rows_abs, rows_flip, rows_dep, pix_weight,
-                                  final_index_alt);
+                                  final_index_alt, out_img_alt);
     for (size_t i = 0; i < I; i++) { /* fixed order: ascending intersection id */
         double *a = acc + (size_t)aux->compact_gid_from_isect[i] * 9;
         double *m = acc_abs + (size_t)aux->compact_gid_from_isect[i] * 9;

@@ -194,6 +194,18 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def sh_basis_for_means(u: dict, means):
+    """Y_k(dir) of gather_grads.wgsl:186-222 for every mean (dir as the shader takes it): [n, (sh_degree + 1)^2] f32."""
+    means = _f32(means)
+    n = means.shape[0]
+    ncoef = (int(u["sh_degree"]) + 1) ** 2
+    Y = np.empty((n, ncoef), np.float32)
+    us = _to_struct(u, n)
+    rc = lib().oracle_sh_basis_for_means(C.byref(us), _p(means), n, _p(Y))
+    assert rc == 0
+    return Y
+
+
 def render_forward(u: dict, means, log_scales, quats, sh_coeffs, raw_opac, raster_u32=False,
                    max_intersects=None):
     """Returns (out_img, aux) with aux a dict of numpy arrays mirroring RenderAux."""
@@ -283,7 +295,7 @@ def rasterize_forward_f64(u: dict, aux: dict):
 
 
 def render_backward_f64(u: dict, aux: dict, means, log_scales, quats, raw_opac, out_img, v_out, pix_weight=None,
-                        final_index_alt=None):
+                        final_index_alt=None, out_img_alt=None):
     """The f64 arbiter (brush_oracle_f64.c): same inputs / forward state, every value in double, the walk's
     decisions as the f32 restatement takes them.  Returns float64 dense grads and, under "mag_<name>", the sum of
     the magnitudes of the terms each element is made of (|f32 result - exact| <= eps_per_term * mag) and, under
@@ -291,7 +303,8 @@ def render_backward_f64(u: dict, aux: dict, means, log_scales, quats, raw_opac, 
     optional): relative uncertainty of each pixel's forward state (T_final); weight x |terms of the pixel| is added
     to the flip allowance (for gradients computed from a different forward state than the one passed here);
     final_index_alt ([h,w] uint32, optional): that other state's final_index — entries only one of the two walks
-    reaches count towards the flip allowance in full."""
+    reaches count towards the flip allowance in full; out_img_alt ([h,w,4] f32, optional): that state's image, from
+    which the difference of the two runs' recovered T behind a stop mismatch is priced."""
     means, log_scales, quats, raw_opac = _f32(means), _f32(log_scales), _f32(quats), _f32(raw_opac)
     out_img, v_out = _f32(out_img), _f32(v_out)
     n = means.shape[0]
@@ -325,5 +338,6 @@ def render_backward_f64(u: dict, aux: dict, means, log_scales, quats, raw_opac, 
                                      _p(None if final_index_alt is None else
                                         np.ascontiguousarray(final_index_alt, np.uint32)),
                                      _p(g["dep_means"]), _p(g["dep_xy"]), _p(g["dep_scales"]), _p(g["dep_quats"]),
-                                     _p(g["dep_sh"]), _p(g["dep_opac"]), _p(g["vjp_sh"]), _p(g["vjp_opac"]))
+                                     _p(g["dep_sh"]), _p(g["dep_opac"]), _p(g["vjp_sh"]), _p(g["vjp_opac"]),
+                                     _p(None if out_img_alt is None else _f32(out_img_alt)))
     return g

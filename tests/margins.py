@@ -47,7 +47,10 @@ def tracked(section, name, tid=None):
 def check_growth(section, name, value, tid=None):
     """Assert `value` (a worst err/tol ratio) has not grown past GROWTH x the tracked one."""
     old = tracked(section, name, tid)
-    if old is None:
+    if old is None or os.environ.get("BRUSH_MARGINS_REBASE"):
+        # REBASE: the run that re-records the margins after the GATE itself changed (new allowance terms or constants);
+        # the allowance is still asserted, only the comparison with the old gate's ratios is skipped.  Never set by the
+        # driver's runs; tools/update_parity_margins.py --note says why a rebase was made.
         return
     old = float(old["worst"] if isinstance(old, dict) else old)
     limit = GROWTH * old + ABS_SLACK

@@ -41,10 +41,10 @@ def test_viewer_and_trainer_threads_share_the_device():
         out, aux, u = R._forward_impl(cam_train, (800, 600), p["means"], p["log_scales"], p["quats"], p["sh"],
                                       p["raw_opac"], False, 8_000_000)
         g, block = R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], C, out, v_out)
-        # entries of compact_gid_from_isect beyond num_intersections are unspecified (allocator leftovers): compare the
-        # defined prefix only
+        # the WHOLE compact_gid_from_isect array is kept: entries at positions >= num_intersections are unspecified
+        # (allocator leftovers, the sort's last pass writes [0, I) only) and must be the ONLY ones that can differ
         I = aux.read_num_intersections()
-        return out, aux.final_index.clone(), aux.compact_gid_from_isect[:I].clone(), aux.tile_bins.clone(), block
+        return out, aux.final_index.clone(), (aux.compact_gid_from_isect.clone(), I), aux.tile_bins.clone(), block
 
     # single-threaded references
     ref_img, ref_v, ref_i = viewer_frame()
@@ -79,7 +79,12 @@ def test_viewer_and_trainer_threads_share_the_device():
     scale = float(ref_block.abs().max())
     for out, fin, cg, bins, block in results["trainer"]:
         assert torch.equal(out, ref_out) and torch.equal(fin, ref_fin)
-        assert torch.equal(cg, ref_cg) and torch.equal(bins, ref_bins)
+        (cg_all, I), (ref_all, ref_I) = cg, ref_cg
+        assert I == ref_I and torch.equal(bins, ref_bins)
+        differing = torch.nonzero(cg_all != ref_all).flatten()
+        # (round 3 saw this comparison fail on the full array: the differing positions were never shown to be the tail)
+        assert differing.numel() == 0 or int(differing.min()) >= I, (int(differing.min()), I, int(differing.numel()))
+        assert torch.equal(cg_all[:I], ref_all[:I])
         # float atomics: summation order differs run to run even single-threaded
         assert float((block - ref_block).abs().max()) <= 1e-4 * scale
     # thread-local error slot: a failing call on one thread does not leak into the other's status
