@@ -112,16 +112,8 @@ size_t sort_workspace_bytes(uint32_t max_n);
 // keys_out == nullptr (internal callers only, bits > 0): the sorted keys themselves are not written (4 B per pair less
 // in the last pass); with an even number of passes the ping-pong puts the LAST pass's keys there, which is the only
 // output dropped.
-// flag_region: the sort's passes are single launches whose workgroups hand their digit counts to each other through
-// per-pass flags at the START of the workspace (sort_flags(ws), sort_flag_words() words).  >= 0: the caller has zeroed
-// ALL of them on this stream since the last sort_launch on this workspace and this sort uses regions flag_region,
-// flag_region + 1, ... (one per pass; the forward: depth sort 0, tile sort 4); < 0: sort_launch zeroes them itself
-// (one memset node).
 hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
                        uint32_t *vals_out, const uint32_t *d_n, uint32_t max_n, uint32_t bits,
-                       void *ws, hipStream_t s, uint32_t *edges = nullptr, uint32_t edge_keys = 0,
-                       int flag_region = -1);
-uint32_t *sort_flags(void *ws);
-uint32_t sort_flag_words();
+                       void *ws, hipStream_t s, uint32_t *edges = nullptr, uint32_t edge_keys = 0);
 
 }  // namespace brush

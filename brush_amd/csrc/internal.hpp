@@ -23,8 +23,7 @@ hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, con
                                const float *quats, const float *sh, const float *raw_opac, float *proj_global,
                                uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
                                uint32_t *gids, uint32_t *bin_edges /* [num_tiles][2], zeroed here */,
-                               const WalkWs &walk, uint32_t *sort_flags /* [sort_flag_words], zeroed here */,
-                               uint32_t sort_flag_words, hipStream_t s);
+                               const WalkWs &walk, hipStream_t s);
 hipError_t launch_project_visible(const ViewParams &vp, const float *proj_global, const uint32_t *num_visible,
                                   uint32_t *global_from_compact, uint32_t *compact_from_global, float *projected,
                                   uint32_t *tiles_hit, const WalkWs &walk, hipStream_t s);

@@ -313,8 +313,7 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                                            uint32_t *__restrict__ overflow,
                                                            uint32_t *__restrict__ tile_bins, uint32_t num_bin_words,
                                                            uint32_t *__restrict__ bin_edges,
-                                                           uint32_t *__restrict__ walk_counter,
-                                                           uint32_t *__restrict__ sort_flags, uint32_t sort_flag_words) {
+                                                           uint32_t *__restrict__ walk_counter) {
     __shared__ uint32_t wave_cnt[kThreads / kWave];
     __shared__ uint32_t vis_list[kThreads / kWave][kCullPerThread * kWave];  // per wave: global ids that passed
     BRUSH_KTRACE(kTrCull, 0);
@@ -331,8 +330,6 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
         tile_bins[i] = 0;  // render.rs:241-244
         bin_edges[i] = 0;  // accumulators of the tile sort's last pass (sort_launch: edges)
     }
-    // hand-off flags of both sorts' chained passes (sort_launch: flag_region)
-    for (uint32_t i = gt; i < sort_flag_words; i += gridDim.x * kThreads) sort_flags[i] = 0;
 
     // Phase A — every splat of the wave's 4 x 64 (round r covers 256 consecutive splats): the two cheap
     // rejections (behind the camera :32, and a conservative screen-bounds test that never changes a
@@ -949,8 +946,7 @@ hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, con
                                uint32_t num_tiles, const float *means, const float *log_scales,
                                const float *quats, const float *sh, const float *raw_opac, float *proj_global,
                                uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
-                               uint32_t *gids, uint32_t *bin_edges, const WalkWs &walk, uint32_t *sort_flags,
-                               uint32_t sort_flag_words, hipStream_t s) {
+                               uint32_t *gids, uint32_t *bin_edges, const WalkWs &walk, hipStream_t s) {
     const uint32_t n = vp.total_splats;
     const uint32_t blocks = (uint32_t)cull_block_count(n);
     uint32_t *compact_from_global = aux.compact_from_global_gid;
@@ -960,7 +956,7 @@ hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, con
     hipLaunchKernelGGL(k_project_cull<D>, dim3(blocks), dim3(kThreads), 0, s, vp, u, means, log_scales, quats, sh, \
                        raw_opac, reinterpret_cast<float4 *>(proj_global), key_all, compact_from_global,          \
                        block_counts, uniforms_buffer, aux.num_intersections, aux.overflow, aux.tile_bins,        \
-                       num_tiles * 2, bin_edges, walk.counter, sort_flags, sort_flag_words)
+                       num_tiles * 2, bin_edges, walk.counter)
     switch (vp.sh_degree) {
         case 0: BRUSH_LAUNCH_CULL(0); break;
         case 1: BRUSH_LAUNCH_CULL(1); break;

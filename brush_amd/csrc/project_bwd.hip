@@ -421,7 +421,7 @@ __device__ __forceinline__ void store_gradients_or_step(
 // depth order wrote the same bytes 35 % slower at 21 M splats (1.73 vs 1.28 ms), the partial lines no longer meeting
 // in the L2.
 template <int DEG>
-__device__ __forceinline__ void zero_invisible_rows(uint32_t n, uint32_t g0, uint32_t lane, uint64_t vis, bool stream_sh,
+__device__ __forceinline__ void zero_invisible_rows(uint32_t n, uint32_t g0, uint32_t lane, uint64_t vis,
                                                     float *__restrict__ v_means, float *__restrict__ v_xy,
                                                     float *__restrict__ v_scales, float *__restrict__ v_quats,
                                                     float *__restrict__ v_sh, float *__restrict__ v_opac) {
@@ -435,10 +435,7 @@ __device__ __forceinline__ void zero_invisible_rows(uint32_t n, uint32_t g0, uin
 #pragma unroll
         for (uint32_t it = 0; it < kPerRow; it++) {
             const uint32_t q = it * kWave + lane;
-            if (q < total && !((vis >> (q / kPerRow)) & 1ull)) {
-                if (stream_sh) nt_store4(sh + (size_t)q * 4, z4);  // wave-uniform choice, see launch_project_backward
-                else *reinterpret_cast<float4 *>(sh + (size_t)q * 4) = z4;
-            }
+            if (q < total && !((vis >> (q / kPerRow)) & 1ull)) nt_store4(sh + (size_t)q * 4, z4);
         }
     } else {
         const uint32_t total = rows * kRow;
@@ -488,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     const float *raw_opac, const uint32_t *__restrict__ compact_from_global,
     const float *__restrict__ v_compact, float *__restrict__ v_means, float *__restrict__ v_xy,
     float *__restrict__ v_scales, float *__restrict__ v_quats, float *__restrict__ v_sh,
-    float *__restrict__ v_opac, AdamFuse af, DetSums det, uint32_t stream_sh) {
+    float *__restrict__ v_opac, AdamFuse af, DetSums det) {
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
     constexpr uint32_t kRow = ncoef * 3;                 // floats per v_sh row
     constexpr uint32_t kRowPad = kRow | 1u;              // odd LDS row stride: conflict-free column access
@@ -528,8 +525,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     const uint32_t g = blockIdx.x * kThreads + li;
     const uint32_t c = threadIdx.x < nvis ? compact_from_global[g] : kInvalid;
     // Dense gradients: the zeros of the invisible splats go out first, so the stores are in flight during the VJP
-    if (!ADAM && g0 < n)
-        zero_invisible_rows<DEG>(n, g0, lane, own_vis, stream_sh != 0u, v_means, v_xy, v_scales, v_quats, v_sh, v_opac);
+    if (!ADAM && g0 < n) zero_invisible_rows<DEG>(n, g0, lane, own_vis, v_means, v_xy, v_scales, v_quats, v_sh, v_opac);
 
     float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_quat[4] = {0.f, 0.f, 0.f, 0.f};
     float o_xy[2] = {0.f, 0.f}, o_opac = 0.f;
@@ -814,7 +810,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_view_records_dense(
                                   }
                               });
     const bool seen = o.stat_count != 0.0f;
-    zero_invisible_rows<DEG>(n, g0, lane, __ballot(seen), true, v_means, nullptr, v_scales, v_quats, v_sh, v_opac);
+    zero_invisible_rows<DEG>(n, g0, lane, __ballot(seen), v_means, nullptr, v_scales, v_quats, v_sh, v_opac);
     if (seen) {
         reinterpret_cast<float4 *>(v_quats)[g] = make_float4(o.quat[0], o.quat[1], o.quat[2], o.quat[3]);
         v_opac[g] = o.opac;
@@ -852,19 +848,15 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
     AdamFuse af{};
     if (adam) af = *adam;
     const DetSums det{dargs.cum_tiles_hit, dargs.num_intersections, dargs.partials, dargs.cap};
-    // zero rows of v_sh: streaming (non-temporal) stores once the dense block outgrows the 256 MB Infinity Cache, ordinary
-    // stores below (tools/ubench/fill_rate.hip: 7.5 vs 6.7 TB/s at 0.27 GB, equal from 1 GB)
-    uint32_t stream_sh = (uint64_t)n * (13u + 3u * (vp.sh_degree + 1u) * (vp.sh_degree + 1u)) * 4u > (320ull << 20) ? 1u : 0u;
-    if (const char *e = getenv("BRUSH_PB_STREAM_SH")) stream_sh = e[0] == '1';  // A/B experiment switch (temporary)
 #define BRUSH_LAUNCH_PB(D)                                                                                      \
     if (adam)                                                                                                   \
         hipLaunchKernelGGL((k_project_backward<D, true>), grid, block, 0, s, vp, means, log_scales, quats,      \
                            raw_opac, compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats, v_sh,    \
-                           v_opac, af, det, stream_sh);                                                         \
+                           v_opac, af, det);                                                                    \
     else                                                                                                        \
         hipLaunchKernelGGL((k_project_backward<D, false>), grid, block, 0, s, vp, means, log_scales, quats,     \
                            raw_opac, compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats, v_sh,    \
-                           v_opac, af, det, stream_sh)
+                           v_opac, af, det)
     switch (vp.sh_degree) {
         case 0: BRUSH_LAUNCH_PB(0); break;
         case 1: BRUSH_LAUNCH_PB(1); break;

@@ -43,14 +43,6 @@ constexpr uint32_t kSortTargetTiles = 128;
 constexpr uint32_t kRadix = 256;
 constexpr uint32_t kMaxTileKeys = kSortThreads * kSortMaxItems;  // 16384
 constexpr uint32_t kFusedMaxTiles = 512;
-// Chained passes: one flag per tile and pass, kSortFlagRegions passes' worth (two sorts of up to 4 passes share a workspace)
-constexpr uint32_t kSortFlagRegions = 8;
-// ... with at most 8 keys per lane (the 16-key variant spills beside the hand-off code): up to 1024 tiles of 8192 keys
-constexpr uint32_t kChainMaxItems = 8;
-constexpr uint32_t kChainMaxTiles = kFusedMaxTiles * kSortMaxItems / kChainMaxItems;
-static_assert(kChainMaxTiles <= kSortThreads, "one polling lane per tile");
-constexpr uint32_t kSortFlagWords = kSortFlagRegions * kChainMaxTiles;
-
 // Sorts larger than that (3-launch shape): fixed 8192-key tiles, scattered by 512-thread workgroups of 16 keys per
 // lane whose LDS image (74 KiB) lets TWO of them share a CU, so one's loads and stores overlap the other's ranking.
 constexpr uint32_t kBigTileKeys = 8192;
@@ -68,10 +60,6 @@ __host__ __device__ __forceinline__ uint32_t sort_items(uint32_t n) {
     uint32_t k = 1;
     while (k < kSortMaxItems && (uint64_t)kSortThreads * k * kSortTargetTiles < n) k <<= 1;
     return k;
-}
-__host__ __device__ __forceinline__ uint32_t chain_items(uint32_t n) {
-    const uint32_t k = sort_items(n);
-    return k < kChainMaxItems ? k : kChainMaxItems;
 }
 // Upper bound of the tile count over every n <= max_n.
 inline uint32_t sort_max_tiles(uint32_t max_n) {
@@ -158,8 +146,6 @@ struct DownLdsT {
     uint32_t digit_base[kRadix];  // global position of the tile's first key of each digit
     uint32_t tile_start[kRadix];  // position inside the tile (after the reorder) of each digit's run
     uint32_t wave_tot2[4][2];
-    uint32_t missing_cnt;              // chained pass: tiles whose counts had not been published when the wait ran out
-    uint16_t missing_list[kChainMaxTiles];
     // FUSED: partial column sums of the count table per row group (keys of earlier tiles / of all tiles).  They live
     // from before barrier A to barrier C, the reordered pairs from barrier C on: same storage.
     static_assert(2 * PARTS * kRadix <= TILE_KEYS, "part / part_all alias keys[]");
@@ -232,100 +218,7 @@ __device__ __forceinline__ void table_sums_to_lds(const uint32_t (&spec)[kSpecRo
     L.part_all()[g8][2 * dp] = ps.all[0], L.part_all()[g8][2 * dp + 1] = ps.all[1];
 }
 
-// ---- chained pass (one launch per pass): hand-off of the tiles' digit counts INSIDE the launch ------------------------
-// Producer: the 128 packed dwords of a tile's row leave as write-through (sc1) stores, every storing wave drains them,
-// the workgroup meets at a barrier and ONE lane sets the tile's flag (agent-scope store).  Consumer: one lane per tile
-// polls that tile's flag with sc1 loads, the workgroup meets at a barrier, then every load of the table is an sc1 load
-// (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms", row 1: one signalling lane per storing
-// workgroup, one workgroup per CU, 4-byte sc1 stores and loads, hipMalloc memory).  The flags of a pass are zeroed
-// before the launch (by the forward's first kernel, or a memset node for the stand-alone sort) and belong to that pass only.
-__device__ __forceinline__ void sc1_store(uint32_t *p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t sc1_load(const uint32_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Digit counts of one tile -> table row (16-bit pairs) + flag.  `hist` = kSortWaves x 256 words of LDS nobody else uses
-// until the next barrier pair.  All 1024 threads call; ends behind a barrier.  Writing a row twice (the owner and a
-// workgroup that ran out of patience, below) stores the same bytes.
-__device__ __forceinline__ void publish_tile_counts(const uint32_t *__restrict__ keys_in, uint32_t n, uint32_t tile,
-                                                    uint32_t items, uint32_t shift, uint32_t mask, uint32_t *hist,
-                                                    uint32_t *__restrict__ table, uint32_t *__restrict__ flags) {
-    for (uint32_t i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) hist[i] = 0;
-    __syncthreads();
-    const uint32_t wid = threadIdx.x / kWave;
-    const uint32_t base = tile * kSortThreads * items;
-    for (uint32_t i = 0; i < items; i++) {
-        const uint32_t idx = base + i * kSortThreads + threadIdx.x;
-        if (idx < n) atomicAdd(&hist[wid * kRadix + ((keys_in[idx] >> shift) & mask)], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < kRadix / 2) {
-        uint32_t c0 = 0, c1 = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kSortWaves; w++) c0 += hist[w * kRadix + 2 * threadIdx.x], c1 += hist[w * kRadix + 2 * threadIdx.x + 1];
-        sc1_store(table + (size_t)tile * (kRadix / 2) + threadIdx.x, c0 | (c1 << 16));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores before the barrier
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) sc1_store(flags + tile, 1u);
-}
-
-// Waits until every tile's counts are published, then sums the table into L.part() / L.part_all().  A workgroup that is
-// not resident cannot publish, and one that spins for it forever would keep it from becoming resident when the device is
-// oversubscribed (several sorts from several streams): a wait that runs out (kChainPatience) makes the waiting workgroup
-// compute the missing rows itself from the input keys and publish them — same bytes, so nobody can tell — and go on.
-// `hist` as in publish_tile_counts.  All 1024 threads call.
-constexpr uint64_t kChainPatience = 3000;  // s_memrealtime ticks of 10 ns
-template <typename LDS>
-__device__ __forceinline__ void chained_table_sums(const uint32_t *__restrict__ keys_in, uint32_t n, uint32_t tile,
-                                                   uint32_t num_tiles, uint32_t items, uint32_t shift, uint32_t mask,
-                                                   uint32_t *hist, uint32_t *__restrict__ table,
-                                                   uint32_t *__restrict__ flags, LDS &L, KTraceRef trace) {
-    if (threadIdx.x < num_tiles) {  // num_tiles <= kChainMaxTiles <= kSortThreads
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        bool seen = sc1_load(flags + threadIdx.x) != 0u;
-        while (!seen && __builtin_amdgcn_s_memrealtime() - t0 < kChainPatience) {
-            __builtin_amdgcn_s_sleep(2);
-            seen = sc1_load(flags + threadIdx.x) != 0u;
-        }
-        if (!seen) L.missing_list[atomicAdd(&L.missing_cnt, 1u)] = (uint16_t)threadIdx.x;
-    }
-    __syncthreads();
-    const uint32_t missing = L.missing_cnt;
-    for (uint32_t m = 0; m < missing; m++)  // block-uniform
-        publish_tile_counts(keys_in, n, L.missing_list[m], items, shift, mask, hist, table, flags);
-    if (missing) {
-        __syncthreads();
-        if (threadIdx.x == 0) L.missing_cnt = 0;
-    }
-    const uint32_t dp = threadIdx.x & (kRadix / 2 - 1), g8 = threadIdx.x / (kRadix / 2);
-    PairSums ps{};
-    constexpr uint32_t kTableLoads = 16;
-    for (uint32_t t0 = g8; t0 < num_tiles; t0 += kTableGroups * kTableLoads) {
-        uint32_t c[kTableLoads];
-#pragma unroll
-        for (uint32_t j = 0; j < kTableLoads; j++) {
-            const uint32_t t = t0 + kTableGroups * j;
-            c[j] = t < num_tiles ? sc1_load(table + (size_t)t * (kRadix / 2) + dp) : 0u;
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < kTableLoads; j++) {
-            const uint32_t b = (t0 + kTableGroups * j) < tile ? c[j] : 0u;
-            ps.all[0] += c[j] & 0xFFFFu, ps.all[1] += c[j] >> 16;
-            ps.below[0] += b & 0xFFFFu, ps.below[1] += b >> 16;
-        }
-    }
-    BRUSH_KTRACE_MARK_VIA(trace, 2, ps.below[0] + ps.all[1]);
-    L.part()[g8][2 * dp] = ps.below[0], L.part()[g8][2 * dp + 1] = ps.below[1];
-    L.part_all()[g8][2 * dp] = ps.all[0], L.part_all()[g8][2 * dp + 1] = ps.all[1];
-    __syncthreads();
-}
-
-// MODE: 0 = large sorts (counts [digit][tile] + totals from the scan kernel), 1 = two launches per pass (table sums
-// from `spec` / `counts` before the ranking), 2 = chained pass (table + flags, summed after the ranking).
-template <int MODE, uint32_t ITEMS, uint32_t THREADS, typename LDS>
+template <bool FUSED, uint32_t ITEMS, uint32_t THREADS, typename LDS>
 __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys_in,
                                                const uint32_t *__restrict__ vals_in,
                                                uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
@@ -333,16 +226,14 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
                                                const uint32_t *__restrict__ counts,
                                                const uint32_t *__restrict__ totals, uint32_t max_tiles,
                                                uint32_t *__restrict__ edges, uint32_t edge_keys, LDS &L,
-                                               const uint32_t (&spec)[kSpecRows], KTraceRef trace = KTraceRef{},
-                                               uint32_t tile = blockIdx.x, uint32_t *chain_table = nullptr,
-                                               uint32_t *chain_flags = nullptr) {
-    constexpr bool FUSED = MODE != 0;
+                                               const uint32_t (&spec)[kSpecRows], KTraceRef trace = KTraceRef{}) {
     static_assert(!FUSED || THREADS == kSortThreads, "the fused table sums assume 8 groups of 128 threads");
     constexpr uint32_t kTileKeys = THREADS * ITEMS;
     constexpr uint32_t kWaves = THREADS / kWave;
     // small sorts: the scatter is a few hundred KB, not worth two barriers — unless the pass also finds the run
     // edges (below), which needs every key's neighbours in output order
     const bool reorder = ITEMS > 2 || edges != nullptr;
+    const uint32_t tile = blockIdx.x;
     const uint32_t wid = threadIdx.x / kWave;
     const uint32_t lane = lane_id();
     for (uint32_t i = threadIdx.x; i < kWaves * kRadix; i += THREADS) (&L.wave_hist[0][0])[i] = 0;
@@ -365,9 +256,9 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
     // FUSED: counts[t][d] (16-bit); the small-tile variants sum their share of the table now, behind the key loads
     // issued above; for the large-tile variants (ITEMS >= 8, register-bound) the kernel did it before the switch.
     uint32_t glob_base = 0, glob_tot = 0;
-    if (MODE == 1) {
+    if (FUSED) {
         if constexpr (ITEMS < 8) table_sums_to_lds(spec, counts, tile, (n + kTileKeys - 1) / kTileKeys, L, trace);
-    } else if (MODE == 0 && threadIdx.x < kRadix) {
+    } else if (threadIdx.x < kRadix) {
         glob_tot = totals[threadIdx.x];
         glob_base = counts[(size_t)threadIdx.x * max_tiles + tile];
     }
@@ -409,9 +300,6 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();  // B: every wave's digit counts are final
-    if constexpr (MODE == 2)  // the other tiles' counts: published before anybody ranked, so normally long there
-        chained_table_sums(keys_in, n, tile, (n + kTileKeys - 1) / kTileKeys, ITEMS, shift, mask, L.vals, chain_table,
-                           chain_flags, L, trace);
     // Threads 0..255 (digit d): 16-wave combine (wave_hist[w][d] <- keys of digit d in earlier waves of the tile),
     // the tile's count of d, and the global sums; then both exclusive scans over the digits behind one pair of
     // barriers: (#keys with a smaller digit anywhere) and (start of the digit's run inside the tile).
@@ -519,7 +407,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     DownLds &L = *reinterpret_cast<DownLds *>(lds_raw);
 #define BRUSH_DOWN(K, SPEC)                                                                                       \
-    downsweep_body<FUSED ? 1 : 0, K, kSortThreads>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, counts, totals, \
+    downsweep_body<FUSED, K, kSortThreads>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, counts, totals, \
                                            max_tiles, edges, edge_keys, L, SPEC, BRUSH_KTRACE_REF)
     if (items >= 8) {  // block-uniform
         // large tiles are register-bound: the table sums are formed here, before their 8 / 16 keys per lane are live
@@ -538,45 +426,6 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_downsweep(
 #undef BRUSH_DOWN
 }
 
-// One launch per pass (sorts of up to kFusedMaxTiles tiles): every workgroup first publishes the digit counts of its
-// tiles (what k_sort_upsweep did in a launch of its own), then scatters them; the counts of the OTHER tiles are picked
-// up after the ranking, by which time they have long been published (chained_table_sums).  At 100 k - 400 k keys a pass
-// was 1.6 + 1.7 us of count kernel + launch boundary beside 5 - 9 us of scatter (profiles/r04a_small_kernel_timeline.json).
-// Grid = min(tiles, kChainGrid): workgroup w takes tiles w, w + grid, ... (only sorts above 4 M keys have more tiles
-// than workgroups).
-constexpr uint32_t kChainGrid = 256;
-__global__ __launch_bounds__(kSortThreads) void k_sort_chained(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ d_n, uint32_t max_n, uint32_t shift, uint32_t mask,
-    uint32_t *__restrict__ table, uint32_t *__restrict__ flags, uint32_t *__restrict__ edges, uint32_t edge_keys) {
-    BRUSH_KTRACE(kTrSortOne, shift | (((shift >> 3) + (max_n > (1u << 21) ? 4u : 0u)) << 24));
-    const uint32_t n = min(*d_n, max_n);
-    BRUSH_KTRACE_MARK(1, n);
-    const uint32_t items = chain_items(n);
-    const uint32_t num_tiles = (uint32_t)(((uint64_t)n + kSortThreads * items - 1) / (kSortThreads * items));
-    if (blockIdx.x >= num_tiles) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    DownLds &L = *reinterpret_cast<DownLds *>(lds_raw);
-    if (threadIdx.x == 0) L.missing_cnt = 0;
-    for (uint32_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x)
-        publish_tile_counts(keys_in, n, tile, items, shift, mask, &L.wave_hist[0][0], table, flags);
-    BRUSH_KTRACE_MARK(3, n);
-    const uint32_t none[kSpecRows] = {};
-#define BRUSH_DOWN(K)                                                                                                 \
-    downsweep_body<2, K, kSortThreads>(keys_in, vals_in, keys_out, vals_out, n, shift, mask, nullptr, nullptr, 0u,  \
-                                       edges, edge_keys, L, none, BRUSH_KTRACE_REF, tile, table, flags)
-    for (uint32_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-        switch (items) {  // block-uniform
-            case 1: BRUSH_DOWN(1); break;
-            case 2: BRUSH_DOWN(2); break;
-            case 4: BRUSH_DOWN(4); break;
-            default: BRUSH_DOWN(8); break;
-        }
-        __syncthreads();  // the next tile's staging overwrites what this one's write-out reads
-    }
-#undef BRUSH_DOWN
-}
-
 // Large sorts: one 8192-key tile per 512-thread workgroup, two workgroups per CU.
 __global__ __launch_bounds__(kBigThreads) void k_sort_downsweep_big(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
@@ -588,7 +437,7 @@ __global__ __launch_bounds__(kBigThreads) void k_sort_downsweep_big(
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     DownLdsBig &L = *reinterpret_cast<DownLdsBig *>(lds_raw);
     const uint32_t no_spec[kSpecRows] = {};
-    downsweep_body<0, kBigTileKeys / kBigThreads, kBigThreads>(keys_in, vals_in, keys_out, vals_out, n, shift,
+    downsweep_body<false, kBigTileKeys / kBigThreads, kBigThreads>(keys_in, vals_in, keys_out, vals_out, n, shift,
                                                                    mask, counts, totals, max_tiles, edges, edge_keys, L,
                                                                    no_spec);
 }
@@ -604,7 +453,6 @@ __global__ void k_sort_copy(const uint32_t *__restrict__ keys_in, const uint32_t
 }
 
 struct SortWs {
-    uint32_t *flags;  // [kSortFlagRegions][kFusedMaxTiles], FIRST: same place whatever max_n the workspace is carved for
     uint32_t *tmp_keys, *tmp_vals, *counts, *totals;
     uint32_t max_tiles;
     size_t bytes;
@@ -613,7 +461,6 @@ struct SortWs {
 SortWs carve_sort(void *ws, uint32_t max_n) {
     SortWs w;
     Carver c(ws);
-    w.flags = c.take<uint32_t>(kSortFlagWords);
     w.max_tiles = sort_max_tiles(max_n ? max_n : 1);
     w.tmp_keys = c.take<uint32_t>(max_n ? max_n : 1);
     w.tmp_vals = c.take<uint32_t>(max_n ? max_n : 1);
@@ -632,9 +479,6 @@ hipError_t enable_big_lds() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLds));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_chained), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(DownLds));
-    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_downsweep_big),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DownLdsBig));
     if (e == hipSuccess) done[dev].store(1, std::memory_order_release);
@@ -645,12 +489,9 @@ hipError_t enable_big_lds() {
 
 size_t sort_workspace_bytes(uint32_t max_n) { return carve_sort(nullptr, max_n).bytes; }
 
-uint32_t *sort_flags(void *ws) { return carve_sort(ws, 1).flags; }
-uint32_t sort_flag_words() { return kSortFlagWords; }
-
 hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
                        uint32_t *vals_out, const uint32_t *d_n, uint32_t max_n, uint32_t bits, void *ws,
-                       hipStream_t s, uint32_t *edges, uint32_t edge_keys, int flag_region) {
+                       hipStream_t s, uint32_t *edges, uint32_t edge_keys) {
     if (max_n == 0) return hipSuccess;
     if (edges && bits == 0) return hipErrorInvalidValue;  // the edges come out of the last pass
     if (!keys_out && (bits == 0 || bits > 16)) return hipErrorInvalidValue;  // only the LAST of <= 2 passes may drop its keys
@@ -665,15 +506,6 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
     const hipError_t lds = enable_big_lds();
     if (lds != hipSuccess) return lds;
     const bool fused = sort_is_fused(max_n);
-    // chained: one launch per pass; the flags of pass p live in region |flag_region| + p.  flag_region < 0: nobody has
-    // zeroed them for this call (stand-alone sort): a memset node does
-    static const bool chained_off = getenv("BRUSH_SORT_TWO_LAUNCHES") != nullptr;  // A/B switch (development)
-    const bool chained = fused && !chained_off && passes <= kSortFlagRegions;
-    const uint32_t region0 = flag_region < 0 ? 0u : (uint32_t)flag_region;
-    if (chained && flag_region < 0) {
-        const hipError_t e = hipMemsetAsync(w.flags, 0, sizeof(uint32_t) * kSortFlagWords, s);
-        if (e != hipSuccess) return e;
-    }
     const uint32_t *src_k = keys_in, *src_v = vals_in;
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t shift = p * 8u;
@@ -683,11 +515,7 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
         uint32_t *dst_k = to_out ? keys_out : w.tmp_keys;  // keys_out may be nullptr: the last pass then writes no keys
         uint32_t *dst_v = to_out ? vals_out : w.tmp_vals;
         uint32_t *pass_edges = p + 1 == passes ? edges : nullptr;
-        if (chained) {
-            hipLaunchKernelGGL(k_sort_chained, dim3(min(2u * w.max_tiles, kChainGrid)), dim3(kSortThreads), sizeof(DownLds), s,
-                               src_k, src_v, dst_k, dst_v, d_n, max_n, shift, mask, w.counts,
-                               w.flags + (size_t)((region0 + p) % kSortFlagRegions) * kChainMaxTiles, pass_edges, edge_keys);
-        } else if (fused) {
+        if (fused) {
             hipLaunchKernelGGL(k_sort_upsweep<true>, dim3(w.max_tiles), dim3(kSortThreads), 0, s, src_k, d_n, max_n,
                                shift, mask, w.counts, w.max_tiles);
             hipLaunchKernelGGL(k_sort_downsweep<true>, dim3(w.max_tiles), dim3(kSortThreads), sizeof(DownLds), s, src_k,

@@ -226,13 +226,12 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
     // (render.rs:102-142)
     BRUSH_HIP_CHECK(launch_project_cull(vp, u, aux, num_tiles, means, log_scales, quats, sh_coeffs, raw_opacity,
                                         ws.proj_global, ws.key_all, ws.block_counts, ws.pre_keys, ws.pre_gids,
-                                        ws.bin_edges, ws.walk, sort_flags(ws.sort_ws), sort_flag_words(), s));
+                                        ws.bin_edges, ws.walk, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_CULL);
     if (stop_behind(BRUSH_STAGE_PROJECT_CULL)) return BRUSH_OK;
     // DepthSort: keys = f32 depth bits, all 32 bits (render.rs:151-156)
-    // (both sorts' hand-off flags were zeroed by the cull kernel: regions 0-3 here, 4-7 for the tile sort)
     BRUSH_HIP_CHECK(sort_launch(ws.pre_keys, ws.pre_gids, ws.sorted_keys, aux.global_from_compact_gid,
-                                aux.num_visible, n, 32, ws.sort_ws, s, nullptr, 0, 0));
+                                aux.num_visible, n, 32, ws.sort_ws, s));
     mark_fwd(s, 1 + BRUSH_STAGE_DEPTH_SORT);
     if (stop_behind(BRUSH_STAGE_DEPTH_SORT)) return BRUSH_OK;
     // ProjectVisible (render.rs:161-184)
@@ -265,7 +264,7 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
     const bool drop_keys = !det && bits <= 16;
     BRUSH_HIP_CHECK(sort_launch(ws.tile_unsorted, det ? nullptr : ws.gid_unsorted, drop_keys ? nullptr : ws.tile_sorted,
                                 det ? aux.isect_unsorted_pos : aux.compact_gid_from_isect, aux.num_intersections, cap,
-                                bits, ws.sort_ws, s, det ? nullptr : ws.bin_edges, num_tiles, 4));
+                                bits, ws.sort_ws, s, det ? nullptr : ws.bin_edges, num_tiles));
     mark_fwd(s, 1 + BRUSH_STAGE_TILE_SORT);
     if (stop_behind(BRUSH_STAGE_TILE_SORT)) return BRUSH_OK;
     if (det)
