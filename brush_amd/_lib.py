@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("BRUSH_HIP_LIB") or os.path.join(_HERE, "lib", "libbru
 
 BRUSH_OK = 0
 AUX_DETERMINISTIC = 1  # BrushAux.flags: BRUSH_AUX_DETERMINISTIC
+AUX_ACCUM_ZEROED = 2   # BrushAux.flags: BRUSH_AUX_ACCUM_ZEROED (backward only)
 UNIFORM_WORDS = 28
 NUM_VISIBLE_WORD = 25
 TILE_WIDTH = 16
@@ -49,6 +50,7 @@ class BrushAux(C.Structure):
         ("max_intersects", C.c_uint32),
         ("isect_unsorted_pos", C.c_void_p),  # deterministic mode only (NULL otherwise)
         ("flags", C.c_uint32),               # AUX_* bits, per call
+        ("bwd_accum", C.c_void_p),           # NULL or the backward's workspace (forward pre-zeroes its accumulators)
     ]
 
 

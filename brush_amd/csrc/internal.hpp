@@ -41,7 +41,9 @@ hipError_t launch_tile_bin_edges(const uint32_t *sorted_tile_ids, const uint32_t
 hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                             const uint32_t *compact_gid_from_isect, uint32_t *tile_bins, const uint32_t *bin_edges,
                             const float *projected, int raster_u32, uint32_t u32_pitch, void *out_img,
-                            uint32_t *final_index, hipStream_t s);
+                            uint32_t *final_index, float *zero_rows /* nullable: [n][kCompactStride], the first
+                            *num_visible rows are zeroed (BrushAux::bwd_accum) */,
+                            const uint32_t *num_visible, uint32_t n, hipStream_t s);
 hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                                      const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
                                      const float *projected, const uint32_t *final_index,

@@ -116,9 +116,17 @@ template <bool RASTER_U32>
 __global__ __launch_bounds__(kRasterThreads) void k_rasterize_quad(
     uint32_t w, uint32_t h, uint32_t tbx, uint32_t num_tiles, const uint32_t *__restrict__ gid_from_isect,
     uint32_t *__restrict__ tile_bins, const uint32_t *__restrict__ bin_edges, const float *__restrict__ projected,
-    void *__restrict__ out_img, uint32_t *__restrict__ final_index, uint32_t u32_pitch) {
+    void *__restrict__ out_img, uint32_t *__restrict__ final_index, uint32_t u32_pitch,
+    float4 *__restrict__ zero_rows, const uint32_t *__restrict__ num_visible, uint32_t n_splats) {
     __shared__ QuadRec lds_all[kTilesPerBlock][kBatch];
     BRUSH_KTRACE(kTrRasterize, 0);
+    if (zero_rows) {
+        // BrushAux::bwd_accum: the backward's compact-order accumulator rows of this render, zeroed here so that the
+        // backward needs no zero-fill launch (fire-and-forget stores beside a kernel that is bound by VALU issue)
+        const uint32_t words = min(*num_visible, n_splats) * kCompactVec;
+        for (uint32_t i = blockIdx.x * kRasterThreads + threadIdx.x; i < words; i += gridDim.x * kRasterThreads)
+            zero_rows[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const uint32_t q = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     QuadRec *lds = lds_all[q];
     const uint32_t tile_id = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-contiguous bands
@@ -597,17 +605,20 @@ __global__ __launch_bounds__(TPB * kWave) void k_rasterize_backward_quad(
 hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                             const uint32_t *compact_gid_from_isect, uint32_t *tile_bins, const uint32_t *bin_edges,
                             const float *projected, int raster_u32, uint32_t u32_pitch, void *out_img,
-                            uint32_t *final_index, hipStream_t s) {
+                            uint32_t *final_index, float *zero_rows, const uint32_t *num_visible, uint32_t n,
+                            hipStream_t s) {
     const uint32_t tiles = tbx * tby;
     if (tiles == 0) return hipSuccess;
     // one workgroup (4 quadrant waves) per tile
     const dim3 grid(ceil_div(tiles, 8u) * 8u), block(kRasterThreads);
     if (raster_u32)
         hipLaunchKernelGGL(k_rasterize_quad<true>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
-                           tile_bins, bin_edges, projected, out_img, final_index, u32_pitch);
+                           tile_bins, bin_edges, projected, out_img, final_index, u32_pitch,
+                           reinterpret_cast<float4 *>(zero_rows), num_visible, n);
     else
         hipLaunchKernelGGL(k_rasterize_quad<false>, grid, block, 0, s, w, h, tbx, tiles, compact_gid_from_isect,
-                           tile_bins, bin_edges, projected, out_img, final_index, u32_pitch);
+                           tile_bins, bin_edges, projected, out_img, final_index, u32_pitch,
+                           reinterpret_cast<float4 *>(zero_rows), num_visible, n);
     return hipGetLastError();
 }
 

@@ -27,6 +27,7 @@ struct BrushProfiler {
     hipEvent_t fwd[kFwdStages + 1];
     hipEvent_t bwd[kBwdStages + 1];
     bool fwd_recorded = false, bwd_recorded = false;
+    uint32_t fwd_mask = 0, bwd_mask = 0;  // events recorded by the last pass (a stage without a launch records none)
     int stop_after = -1;  // brush_profiler_stop_after: the pass ends behind this stage, no events
 };
 
@@ -38,13 +39,17 @@ static inline bool stop_behind(int stage) { return g_prof && g_prof->stop_after 
 
 static inline void mark_fwd(hipStream_t s, int idx) {
     if (g_prof && g_prof->stop_after < 0) {
+        if (idx == 0) g_prof->fwd_mask = 0;
         (void)hipEventRecord(g_prof->fwd[idx], s);
+        g_prof->fwd_mask |= 1u << idx;
         if (idx == BrushProfiler::kFwdStages) g_prof->fwd_recorded = true;
     }
 }
 static inline void mark_bwd(hipStream_t s, int idx) {
     if (g_prof && g_prof->stop_after < 0) {
+        if (idx == 0) g_prof->bwd_mask = 0;
         (void)hipEventRecord(g_prof->bwd[idx], s);
+        g_prof->bwd_mask |= 1u << idx;
         if (idx == BrushProfiler::kBwdStages) g_prof->bwd_recorded = true;
     }
 }
@@ -122,7 +127,7 @@ BwdWs carve_bwd(void *ws, uint32_t n, uint32_t cap, bool det) {
 inline bool aux_det(const BrushAux &a) { return (a.flags & BRUSH_AUX_DETERMINISTIC) != 0; }
 
 bool aux_ok(const BrushAux *a, bool need_final_index) {
-    if (a && (a->flags & ~BRUSH_AUX_DETERMINISTIC) != 0) return false;  // unknown flag bits
+    if (a && (a->flags & ~(BRUSH_AUX_DETERMINISTIC | BRUSH_AUX_ACCUM_ZEROED)) != 0) return false;  // unknown flag bits
     if (a && aux_det(*a) && !a->isect_unsorted_pos) return false;
     return a && a->projected_splats && a->uniforms_buffer && a->num_intersections && a->num_visible &&
            (a->final_index || !need_final_index) && a->cum_tiles_hit && a->tile_bins &&
@@ -267,15 +272,18 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
                                 bits, ws.sort_ws, s, det ? nullptr : ws.bin_edges, num_tiles));
     mark_fwd(s, 1 + BRUSH_STAGE_TILE_SORT);
     if (stop_behind(BRUSH_STAGE_TILE_SORT)) return BRUSH_OK;
-    if (det)
+    if (det) {
         BRUSH_HIP_CHECK(launch_tile_bin_edges(ws.tile_sorted, aux.num_intersections, cap, aux.tile_bins,
                                               aux.isect_unsorted_pos, ws.gid_unsorted, aux.compact_gid_from_isect, s));
-    mark_fwd(s, 1 + BRUSH_STAGE_TILE_BINS);
+        mark_fwd(s, 1 + BRUSH_STAGE_TILE_BINS);
+    }  // default mode: the stage has no launch (the edges come out of the tile sort), so it records no event either
     if (stop_behind(BRUSH_STAGE_TILE_BINS)) return BRUSH_OK;
     // Rasterize (render.rs:267-307)
+    // (default mode, aux.bwd_accum given: the kernel also zeroes the backward's accumulator rows, BRUSH_AUX_ACCUM_ZEROED)
     BRUSH_HIP_CHECK(launch_rasterize(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
                                      det ? nullptr : ws.bin_edges, aux.projected_splats, raster_u32,
-                                     u32_pitch ? u32_pitch : w, out_img, aux.final_index, s));
+                                     u32_pitch ? u32_pitch : w, out_img, aux.final_index,
+                                     det ? nullptr : aux.bwd_accum, aux.num_visible, n, s));
     mark_fwd(s, 1 + BRUSH_STAGE_RASTERIZE);
     return BRUSH_OK;
 }
@@ -307,7 +315,7 @@ static int composite_backward(const BrushUniforms &u, const BrushAux &aux, const
                               uint32_t n, const BwdWs &ws, DetSumsArgs *det, hipStream_t s) {
     const uint32_t w = u.img_size[0], h = u.img_size[1], tbx = u.tile_bounds[0], tby = u.tile_bounds[1];
     if (ws.rows) {
-        mark_bwd(s, 1);  // no zero-fill stage in this mode
+        // no zero-fill stage in this mode: no launch, no event
         BRUSH_HIP_CHECK(launch_rasterize_backward(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
                                                   aux.projected_splats, aux.final_index, out_img, v_out, ws.v_compact,
                                                   aux.isect_unsorted_pos, ws.rows, s));
@@ -320,9 +328,12 @@ static int composite_backward(const BrushUniforms &u, const BrushAux &aux, const
         det->cap = aux.max_intersects;
         return BRUSH_OK;
     }
-    // compact-order accumulators are atomically added to: zero the first V rows (render.rs:505-507)
-    BRUSH_HIP_CHECK(launch_zero_compact_grads(aux.num_visible, n, ws.v_compact, s));
-    mark_bwd(s, 1);
+    // compact-order accumulators are atomically added to: zero the first V rows (render.rs:505-507) — unless the
+    // forward of this render already did (BrushAux::bwd_accum + BRUSH_AUX_ACCUM_ZEROED)
+    if (!(aux.flags & BRUSH_AUX_ACCUM_ZEROED)) {
+        BRUSH_HIP_CHECK(launch_zero_compact_grads(aux.num_visible, n, ws.v_compact, s));
+        mark_bwd(s, 1);
+    }
     if (stop_behind(BRUSH_STAGE_BWD_ZERO)) return BRUSH_OK;
     BRUSH_HIP_CHECK(launch_rasterize_backward(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
                                               aux.projected_splats, aux.final_index, out_img, v_out, ws.v_compact,
@@ -343,6 +354,7 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
     const BrushAux &aux = *h_aux;
     const BwdWs ws = carve_bwd(workspace, n, aux.max_intersects, aux_det(aux));
     if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
+    if ((aux.flags & BRUSH_AUX_ACCUM_ZEROED) && !aux_det(aux) && aux.bwd_accum != ws.v_compact) return BRUSH_ERR_INVALID_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     BrushUniforms u = *h_uniforms;
@@ -432,6 +444,7 @@ extern "C" int brush_render_backward_records(const BrushUniforms *h_uniforms, co
     const BrushAux &aux = *h_aux;
     const BwdWs ws = carve_bwd(workspace, n, aux.max_intersects, aux_det(aux));
     if (workspace_bytes < ws.bytes) return BRUSH_ERR_WORKSPACE_SMALL;
+    if ((aux.flags & BRUSH_AUX_ACCUM_ZEROED) && !aux_det(aux) && aux.bwd_accum != ws.v_compact) return BRUSH_ERR_INVALID_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     BrushUniforms u = *h_uniforms;
     u.total_splats = n;
@@ -555,15 +568,24 @@ extern "C" void brush_profiler_attach(BrushProfiler *p) { g_prof = p; }
 extern "C" int brush_profiler_read(BrushProfiler *p, float *h_ms) {
     if (!p || !h_ms) return BRUSH_ERR_INVALID_ARG;
     for (int i = 0; i < BRUSH_NUM_STAGES; i++) h_ms[i] = 0.0f;
+    // a stage that launched nothing recorded no event: it reads 0 and the next stage is measured from the last event
     if (p->fwd_recorded) {
         BRUSH_HIP_CHECK(hipEventSynchronize(p->fwd[BrushProfiler::kFwdStages]));
-        for (int i = 0; i < BrushProfiler::kFwdStages; i++)
-            BRUSH_HIP_CHECK(hipEventElapsedTime(&h_ms[i], p->fwd[i], p->fwd[i + 1]));
+        int last = 0;
+        for (int i = 0; i < BrushProfiler::kFwdStages; i++) {
+            if (!((p->fwd_mask >> (i + 1)) & 1u)) continue;
+            BRUSH_HIP_CHECK(hipEventElapsedTime(&h_ms[i], p->fwd[last], p->fwd[i + 1]));
+            last = i + 1;
+        }
     }
     if (p->bwd_recorded) {
         BRUSH_HIP_CHECK(hipEventSynchronize(p->bwd[BrushProfiler::kBwdStages]));
-        for (int i = 0; i < BrushProfiler::kBwdStages; i++)
-            BRUSH_HIP_CHECK(hipEventElapsedTime(&h_ms[BrushProfiler::kFwdStages + i], p->bwd[i], p->bwd[i + 1]));
+        int last = 0;
+        for (int i = 0; i < BrushProfiler::kBwdStages; i++) {
+            if (!((p->bwd_mask >> (i + 1)) & 1u)) continue;
+            BRUSH_HIP_CHECK(hipEventElapsedTime(&h_ms[BrushProfiler::kFwdStages + i], p->bwd[last], p->bwd[i + 1]));
+            last = i + 1;
+        }
     }
     return BRUSH_OK;
 }

@@ -262,9 +262,7 @@ class ViewExchange:
         nbytes = C.c_size_t()
         _lib.check(l.brush_bwd_workspace_size_flags(n, w, h, int(u.sh_degree), int(aux.max_intersects), int(aux.flags),
                                                     C.byref(nbytes)), "brush_bwd_workspace_size_flags")
-        if getattr(self, "_ws", None) is None or self._ws.numel() < nbytes.value:
-            self._ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=self.device)
-        s = aux._as_struct()
+        self._ws, s = aux.backward_workspace(nbytes.value, self.device)
         with torch.cuda.device(self.device):
             _lib.check(l.brush_render_backward_records(C.byref(u), C.byref(s), means.data_ptr(), log_scales.data_ptr(),
                                                        quats.data_ptr(), raw_opacity.data_ptr(), n, out_img.data_ptr(),

@@ -75,10 +75,28 @@ class RenderAux:
     # deterministic mode only: pre-sort position of every sorted intersection
     isect_unsorted_pos: Optional[torch.Tensor] = None
     flags: int = 0                         # BrushAux.flags this render ran with (forward and backward agree)
+    # default mode: the backward's workspace, allocated at forward time so that the forward's last kernel zeroes the
+    # accumulator rows (BrushAux::bwd_accum); `bwd_ws_zeroed` is consumed by the first backward of this render
+    bwd_ws: Optional[torch.Tensor] = None
+    bwd_ws_zeroed: bool = False
 
     @property
     def deterministic(self) -> bool:
         return bool(self.flags & _lib.AUX_DETERMINISTIC)
+
+    def backward_workspace(self, nbytes: int, device):
+        """(workspace tensor, BrushAux struct) for ONE backward call of this render: the buffer the forward pre-zeroed
+        (with BRUSH_AUX_ACCUM_ZEROED set, first backward only) or a fresh one."""
+        s = self._as_struct()
+        if self.bwd_ws is not None and self.bwd_ws.numel() >= nbytes:
+            ws = self.bwd_ws
+            if self.bwd_ws_zeroed:
+                s.flags |= _lib.AUX_ACCUM_ZEROED
+                self.bwd_ws_zeroed = False  # a second backward of the same forward zero-fills itself
+        else:
+            ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+            s.bwd_accum = None
+        return ws, s
 
     def read_num_visible(self) -> int:
         """lib.rs:42-47 (a host readback; not on the hot path)."""
@@ -101,6 +119,7 @@ class RenderAux:
         s.max_intersects = int(self.max_intersects)
         s.isect_unsorted_pos = None if self.isect_unsorted_pos is None else self.isect_unsorted_pos.data_ptr()
         s.flags = int(self.flags)
+        s.bwd_accum = None if self.bwd_ws is None else self.bwd_ws.data_ptr()
         return s
 
 
@@ -141,7 +160,9 @@ def _check_inputs(means, xy_dummy, log_scales, quats, sh_coeffs, raw_opacity):
 
 def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, raw_opacity, render_u32: bool,
                   max_intersects: Optional[int], row_pitch: Optional[int] = None,
-                  deterministic: Optional[bool] = None):
+                  deterministic: Optional[bool] = None, expect_backward: Optional[bool] = None):
+    """expect_backward (default: a float image in default mode): allocate the backward's workspace now and let the
+    forward zero its accumulator rows, so that the backward of this render needs no zero-fill launch."""
     l = _lib.lib()
     det = deterministic_default() if deterministic is None else bool(deterministic)
     n = means.shape[0]
@@ -176,6 +197,14 @@ def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, ra
         out = torch.zeros((h, int(row_pitch), 1), dtype=i32, device=dev)  # padding columns stay 0 (burn_texture.rs:21-24)
     else:
         out = _empty((h, w, 1), i32, dev) if render_u32 else _empty((h, w, 4), torch.float32, dev)
+    if expect_backward is None:
+        expect_backward = not render_u32
+    if expect_backward and not det and not render_u32:
+        bbytes = C.c_size_t()
+        _lib.check(l.brush_bwd_workspace_size_flags(n, w, h, sh_degree, cap, int(aux.flags), C.byref(bbytes)),
+                   "brush_bwd_workspace_size_flags")
+        aux.bwd_ws = _empty((max(bbytes.value, 1),), torch.uint8, dev)
+        aux.bwd_ws_zeroed = True
     nbytes = C.c_size_t()
     _lib.check(l.brush_fwd_workspace_size(n, w, h, sh_degree, cap, C.byref(nbytes)), "brush_fwd_workspace_size")
     ws = _empty((max(nbytes.value, 1),), torch.uint8, dev)
@@ -234,9 +263,8 @@ def _backward_impl(u, aux: RenderAux, means, log_scales, quats, raw_opacity, nco
     nbytes = C.c_size_t()
     _lib.check(l.brush_bwd_workspace_size_flags(n, w, h, int(u.sh_degree), int(aux.max_intersects), int(aux.flags),
                                                 C.byref(nbytes)), "brush_bwd_workspace_size_flags")
-    ws = _empty((max(nbytes.value, 1),), torch.uint8, dev)
     v_out = v_out.contiguous()
-    s = aux._as_struct()
+    ws, s = aux.backward_workspace(nbytes.value, dev)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream().cuda_stream
         _lib.check(l.brush_render_backward(C.byref(u), C.byref(s), means.data_ptr(), log_scales.data_ptr(),
@@ -289,7 +317,8 @@ def render_splats(cam: Camera, img_size, means: torch.Tensor, xy_grad_dummy: Opt
         # UnTracked branch (render.rs:453-460): plain forward, no state kept.
         with torch.no_grad():
             out, aux, _ = _forward_impl(cam, img_size, means, log_scales, quats, sh_coeffs, raw_opacity,
-                                        render_u32_buffer, max_intersects, deterministic=deterministic)
+                                        render_u32_buffer, max_intersects, deterministic=deterministic,
+                                        expect_backward=False)
         return out, aux
     if xy_grad_dummy is None:
         xy_grad_dummy = torch.zeros((means.shape[0], 2), dtype=torch.float32, device=means.device)

@@ -258,9 +258,8 @@ class SplatTrainer:
                 _lib.check(l.brush_bwd_workspace_size_flags(n, w, h, int(u.sh_degree), int(aux.max_intersects),
                                                             int(aux.flags), C.byref(nbytes)),
                            "brush_bwd_workspace_size_flags")
-                ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=means.device)
+                ws, s_aux = aux.backward_workspace(nbytes.value, means.device)
                 v_xy = torch.empty((max(n, 1), 2), dtype=torch.float32, device=means.device)
-                s_aux = aux._as_struct()
                 next_rot = torch.empty_like(quats)
                 _lib.check(l.brush_render_backward_adam(C.byref(u), C.byref(s_aux), C.byref(cfg), means.data_ptr(),
                                                         log_scales.data_ptr(), norm_rot.data_ptr(), quats.data_ptr(),

@@ -91,7 +91,15 @@ typedef struct BrushAux {
                                           the backward to sum a splat's per-tile gradient rows in a fixed order.
                                           Must be non-NULL in that mode, ignored otherwise. */
     uint32_t flags;                    /* BRUSH_AUX_* bits, chosen PER CALL; the forward and the backward of one
-                                          render must be given the same value */
+                                          render must be given the same BRUSH_AUX_DETERMINISTIC bit */
+    float *bwd_accum;                  /* NULL, or the buffer the caller will pass as `workspace` to the backward of
+                                          this render (brush_bwd_workspace_size* bytes).  Default mode only: the
+                                          forward's last kernel then also zeroes the backward's per-splat accumulator
+                                          rows (the first num_visible 64-byte rows of that buffer), and a backward
+                                          called with BRUSH_AUX_ACCUM_ZEROED skips its zero-fill launch.  The
+                                          reference zero-fills inside the backward (render.rs:505-507); at 100 k
+                                          visible splats that launch is 6 us of a 345 us step for 6.6 MB of stores the
+                                          VALU-bound compositing kernel carries for free. */
 } BrushAux;
 
 /* BrushAux::flags */
@@ -101,6 +109,10 @@ typedef struct BrushAux {
                                       reference's CAS queue, rasterize_backwards.wgsl:276-301, has the same
                                       nondeterminism).  Needs isect_unsorted_pos and the larger backward workspace
                                       of brush_bwd_workspace_size_flags. */
+#define BRUSH_AUX_ACCUM_ZEROED 2u  /* backward only, default mode: `workspace` == aux.bwd_accum of the forward of this
+                                      render, nothing has written to it since, and no backward has consumed it yet
+                                      (the FIRST backward after that forward): the accumulators are already zero.  A
+                                      second backward of the same forward must clear the bit (it zero-fills itself). */
 
 /* ---- introspection ------------------------------------------------------------------ */
 const char *brush_version(void);

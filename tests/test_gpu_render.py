@@ -751,6 +751,61 @@ def test_headline_size_properties(dev):
     assert float((xy1.double() * 2 - xy2.double()).abs().max()) <= 1e-4 * (float(xy2.abs().max()) + 1e-30)
 
 
+def test_forward_prezeroes_the_backward_accumulators(dev):
+    """Build extension BrushAux::bwd_accum + BRUSH_AUX_ACCUM_ZEROED: the forward's last kernel zeroes the backward's
+    accumulator rows, the first backward of that render skips its zero-fill launch, a SECOND backward of the same forward
+    zero-fills itself, and a backward that claims pre-zeroed accumulators in another buffer is refused."""
+    import ctypes as C
+
+    import torch
+
+    from brush_amd import _lib
+    from brush_amd import render as R
+
+    n, w, h, deg = 60_000, 400, 300, 2
+    ncoef = (deg + 1) ** 2
+    cloud = H.synthetic_cloud(n, deg, seed=21, mean_mult=0.02)
+    p = {k: _t(v, dev) for k, v in cloud.items()}
+    cam = _camera(w, h)
+    v_out = torch.randn((h, w, 4), device=dev) / (h * w)
+
+    def run(expect):
+        out, aux, u = R._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"], False,
+                                      2_000_000, expect_backward=expect)
+        return out, aux, u
+
+    out0, aux0, u0 = run(False)
+    assert aux0.bwd_ws is None
+    _, ref = R._backward_impl(u0, aux0, p["means"], p["log_scales"], p["quats"], p["raw_opac"], ncoef, out0, v_out)
+    out1, aux1, u1 = run(True)
+    assert aux1.bwd_ws is not None and aux1.bwd_ws_zeroed and torch.equal(out0, out1)
+    V = aux1.read_num_visible()
+    # what the forward left in the accumulator rows: exact zeros (the buffer was poisoned when it was allocated)
+    rows = aux1.bwd_ws[:V * 64].view(torch.float32)
+    assert V > 1000 and not bool(rows.any())
+    _, g1 = R._backward_impl(u1, aux1, p["means"], p["log_scales"], p["quats"], p["raw_opac"], ncoef, out1, v_out)
+    assert not aux1.bwd_ws_zeroed
+    _, g2 = R._backward_impl(u1, aux1, p["means"], p["log_scales"], p["quats"], p["raw_opac"], ncoef, out1, v_out)
+    scale = float(ref.abs().max())
+    assert scale > 0
+    for g in (g1, g2):  # float atomics: two runs differ in the last bits
+        assert float((g - ref).abs().max()) <= 1e-4 * scale
+    # the flag with a workspace that is not the one the forward zeroed: refused
+    out2, aux2, u2 = run(True)
+    s = aux2._as_struct()
+    s.flags |= _lib.AUX_ACCUM_ZEROED
+    other = torch.empty_like(aux2.bwd_ws)
+    blk = torch.zeros(R.grad_block_layout(n, ncoef)[1], device=dev)
+    lay, _ = R.grad_block_layout(n, ncoef)
+    ptr = lambda name: blk.data_ptr() + 4 * lay[name][0]
+    rc = _lib.lib().brush_render_backward(C.byref(u2), C.byref(s), p["means"].data_ptr(), p["log_scales"].data_ptr(),
+                                          p["quats"].data_ptr(), p["raw_opac"].data_ptr(), n, out2.data_ptr(),
+                                          v_out.data_ptr(), ptr("v_means"), ptr("v_xy"), ptr("v_scales"), ptr("v_quats"),
+                                          ptr("v_sh"), ptr("v_opac"), other.data_ptr(), other.numel(),
+                                          torch.cuda.current_stream().cuda_stream)
+    assert rc == -1  # BRUSH_ERR_INVALID_ARG
+
+
 def test_rejects_bad_shapes(dev):
     import torch
 
