@@ -10,9 +10,10 @@ and the step ends with the SUM of the per-view parameter gradients on every rank
 default through an RCCL all-gather of 64-byte per-visible-splat records and a deterministic
 per-splat reduction (brush_amd/dist.py), with --dense-allreduce through one all-reduce of the dense
 block; scaling is weak (per-GPU work fixed).  Rank 0 prints ONE JSON line; `train` in it is the full
-training iteration (loss + Adam) at the same N.  At N=1 `value` is the K steps replayed as one captured hipGraph after
-W warm-up replays (the launch mode of every earlier round's number); the same K steps as eager launches through the
-C ABI are timed beside it (`whole_path.eager_ms_per_step`).  `stage_ms` are IN-SITU stage times: the captured prefixes
+training iteration (loss + Adam) at the same N.  At N=1 `value` is ONE fixed launch mode: the K steps as eager launches
+through the C ABI after W warm-up steps — how the reference's host drives its kernels, and the mode BENCH_r03's value was
+in (0.3475 ms; r01 / r02 quoted a hipGraph replay).  The same K steps replayed as one captured hipGraph are timed beside
+it (`whole_path.graph_ms_per_step`; r02 0.374, r03 0.354-0.356 ms), so both series can be followed round to round.  `stage_ms` are IN-SITU stage times: the captured prefixes
 cull .. stage k of the step are timed as replayed graphs and differenced (brush_profiler_stop_after), so they add up to
 the step; `stage_ms_events` are the hipEvent times of eager passes that earlier rounds reported (every event record adds
 ~3-5 us to its stage).  At N>1 the three gradient-exchange forms (records padded / records packed / dense all-reduce)
@@ -249,10 +250,12 @@ def main():
     wl = Workload(p, n, w, h, cam, cap)
     exchange_mode = None
     exchange_variants = None
+    graph_ms = None
     if world == 1:
-        if not args.no_graph:
+        if not args.no_graph:  # the same K steps as one replayed hipGraph, reported beside the headline
             wl.capture()
-        step = wl.step
+            graph_ms = timed(wl.step, args.steps, args.warmup) * 1e3 / args.steps
+        step = wl.fwd_bwd
         elapsed = timed(step, args.steps, args.warmup)
     else:
         # N > 1: one view per rank; the step ends with the SUM of the per-view parameter gradients on every rank.  Three
@@ -315,14 +318,8 @@ def main():
     overflow = int(aux.overflow.item())
     P, T = w * h, (-(-w // 16)) * (-(-h // 16))
 
-    # the same fwd+bwd as eager launches (host enqueue cost included), N=1 only: the same K steps after the same W
-    # warm-up steps.  `value` stays the graph replay (as in every earlier round); `whole_path` keeps both times.
-    eager_ms = graph_ms = None
+    eager_ms = ms_per_step if world == 1 else None
     launch_used = None
-    if world == 1 and wl.graph is not None:
-        graph_ms = ms_per_step
-        eager_elapsed = timed(wl.fwd_bwd, args.steps, args.warmup)
-        eager_ms = eager_elapsed * 1e3 / args.steps
 
     # ---- per-stage device time (hipEvents on the op's stream), separate untimed steps ----
     def profile_stages(workload, steps):
@@ -499,9 +496,8 @@ def main():
                 pp = {k: torch.as_tensor(v, device=dev) for k, v in cl.items()}
                 del cl
                 x = Workload(pp, c["n"], c["w"], c["h"], view_camera(0, c["w"], c["h"]), c["cap"])
-                x.capture()
-                sec = timed(x.step, c["steps"], 2)
-                ax = x.step()
+                sec = timed(x.fwd_bwd, c["steps"], 2)  # eager launches, like the headline
+                ax = x.fwd_bwd()
                 torch.cuda.synchronize()
                 Vx, Ix = ax.read_num_visible(), ax.read_num_intersections()
                 Px, Tx = c["w"] * c["h"], (-(-c["w"] // 16)) * (-(-c["h"] // 16))
@@ -550,8 +546,8 @@ def main():
                                   f"algorithm, OpenMP; not wgpu/lavapipe), {cpu_s * 1e3:.0f} ms/view"}
 
     if rank == 0:
-        launch = launch_used if launch_used else "eager" if args.no_graph else (
-            "hipGraph replay of one fwd+bwd" if world == 1 else
+        launch = launch_used if launch_used else (
+            "eager launches through the C ABI (hipGraph replay of the same step: whole_path.graph_ms_per_step)" if world == 1 else
             "record forms: hipGraph replay of the forward, then backward, exchange and reduction enqueued per step; dense "
             "all-reduce form: eager launches")
         line = {
