@@ -44,13 +44,28 @@ hipError_t launch_rasterize(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                             uint32_t *final_index, float *zero_rows /* nullable: [n][kCompactStride], the first
                             *num_visible rows are zeroed (BrushAux::bwd_accum) */,
                             const uint32_t *num_visible, uint32_t n, hipStream_t s);
+// Zero-fill the compositing backward carries beside its arithmetic: the dense gradient arrays of the same backward
+// (render.rs:539-547,573-575 zero-fills them with separate launches).  The kernel is bound by VALU issue and moves
+// little memory, so its waves store the zeros in passing, one KiB (64 lanes x 16 B) per wave instruction, paced over
+// the records they walk; the parameter VJP kernel behind it then writes the visible splats' rows only.
+constexpr uint32_t kFillSegs = 6;
+struct ZeroFill {
+    float *base[kFillSegs];                // 16-byte aligned array starts
+    uint32_t full[kFillSegs];              // whole 16-byte chunks of the array
+    uint32_t tail[kFillSegs];              // floats behind them (0..3)
+    uint32_t first_block[kFillSegs + 1];   // cumulative KiB blocks (the last block of an array may be partial)
+    __host__ __device__ bool active() const { return first_block[kFillSegs] != 0u; }
+};
+// Fills `zf` for the given arrays (nullptr / 0 floats: skipped).  False — and an inactive `zf` — when an array is not
+// 16-byte aligned or too large for 32-bit chunk counts: the caller then keeps the zeros in the VJP kernel.
+bool make_zero_fill(ZeroFill *zf, float *const *arrays, const size_t *floats, uint32_t count);
 hipError_t launch_rasterize_backward(uint32_t w, uint32_t h, uint32_t tbx, uint32_t tby,
                                      const uint32_t *compact_gid_from_isect, const uint32_t *tile_bins,
                                      const float *projected, const uint32_t *final_index,
                                      const float *out_img, const float *v_out, float *v_compact,
                                      const uint32_t *unsorted_pos /* deterministic mode, else nullptr */,
                                      float *rows /* deterministic mode: [max_intersects][12], else nullptr */,
-                                     hipStream_t s);
+                                     const ZeroFill &fill, hipStream_t s);
 
 // project_bwd.hip
 // Optimizer state for the fused backward + Adam form (brush_render_backward_adam).
@@ -80,7 +95,10 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
                                    const uint32_t *compact_from_global, const float *v_compact,
                                    float *v_means, float *v_xy,
                                    float *v_scales, float *v_quats, float *v_sh, float *v_opac,
-                                   const AdamFuse *adam, const DetSumsArgs &det, hipStream_t s);
+                                   const AdamFuse *adam, const DetSumsArgs &det,
+                                   bool prezeroed /* dense form only: the arrays are already zero (ZeroFill), the
+                                   visible splats' rows alone are written */,
+                                   hipStream_t s);
 // View-sharded data parallelism (project_bwd.hip): per-view 64-byte gradient records, their index by global id and
 // the deterministic per-splat sum over views (dense arrays, or straight into the Adam update when adam != nullptr).
 hipError_t launch_project_backward_records(const ViewParams &vp, const float *means, const float *log_scales,

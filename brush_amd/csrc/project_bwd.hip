@@ -470,6 +470,69 @@ __device__ __forceinline__ void zero_invisible_rows(uint32_t n, uint32_t g0, uin
     }
 }
 
+// GatherGrads + ProjectBackwards of one visible splat `g` from its compact-order sums (r0, r1, r2): the parameter
+// gradients and the factors of its v_sh row (Y[k] * vcol).  Shared by the dense kernels; same expression trees in both.
+template <int DEG>
+__device__ __forceinline__ void visible_splat_vjp(const ViewParams &vp, const float *means, const float *log_scales,
+                                                  const float *__restrict__ quats, const float *raw_opac, uint32_t g,
+                                                  const float4 r0, const float4 r1, const float4 r2, float o_mean[3],
+                                                  float o_scale[3], float o_quat[4], float &o_opac, float o_xy[2],
+                                                  float vcol[3], float *Y) {
+    constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1);
+    const float vxy[2] = {r0.x, r0.y};
+    const float vconic[3] = {r0.z, r0.w, r1.x};
+    vcol[0] = r1.y;
+    vcol[1] = r1.z;
+    vcol[2] = r1.w;
+    const float v_alpha_sum = r2.x;
+
+    const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
+    const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
+                            det_expf(log_scales[(size_t)g * 3 + 2])};
+    const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
+    const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+
+    // ---- GatherGrads (gather_grads.wgsl:174-231)
+    float dir[3];
+    view_dir(vp, mean, dir);
+    sh_basis<ncoef>(DEG, dir, Y);
+    const float sg = det_sigmoid(raw_opac[g]);
+    o_opac = v_alpha_sum * (sg * (1.0f - sg));
+    o_xy[0] = vxy[0];
+    o_xy[1] = vxy[1];
+
+    // ---- ProjectBackwards (project_backwards.wgsl:83-226)
+    splat_projection_vjp(vp, mean, scale, quat, vxy, vconic, o_mean, o_scale, o_quat);
+}
+
+// The dense-gradient rows of visible splat `g`, written by the lane that computed them.
+template <int DEG>
+__device__ __forceinline__ void store_visible_rows(uint32_t g, const float o_mean[3], const float o_scale[3],
+                                                   const float o_quat[4], float o_opac, const float o_xy[2],
+                                                   const float vcol[3], const float *Y, float *__restrict__ v_means,
+                                                   float *__restrict__ v_xy, float *__restrict__ v_scales,
+                                                   float *__restrict__ v_quats, float *__restrict__ v_sh,
+                                                   float *__restrict__ v_opac) {
+    constexpr uint32_t kRow = (DEG + 1) * (DEG + 1) * 3;  // floats per v_sh row
+    const size_t gg = g;
+    if (v_xy) reinterpret_cast<float2 *>(v_xy)[gg] = make_float2(o_xy[0], o_xy[1]);
+    reinterpret_cast<float4 *>(v_quats)[gg] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
+    v_opac[gg] = o_opac;
+#pragma unroll
+    for (int k = 0; k < 3; k++) v_means[gg * 3 + k] = o_mean[k], v_scales[gg * 3 + k] = o_scale[k];
+    float *row = v_sh + gg * kRow;  // v_sh row = Y[k] * v_rgb (gather_grads.wgsl:186-222)
+    if constexpr (kRow % 4 == 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < kRow / 4; j++)
+            reinterpret_cast<float4 *>(row)[j] =
+                make_float4(Y[(4 * j) / 3] * vcol[(4 * j) % 3], Y[(4 * j + 1) / 3] * vcol[(4 * j + 1) % 3],
+                            Y[(4 * j + 2) / 3] * vcol[(4 * j + 2) % 3], Y[(4 * j + 3) / 3] * vcol[(4 * j + 3) % 3]);
+    } else {
+#pragma unroll
+        for (uint32_t e = 0; e < kRow; e++) row[e] = Y[e / 3] * vcol[e % 3];
+    }
+}
+
 // ADAM: instead of storing the dense parameter gradients, every element goes straight through the
 // optimizer update of its parameter (brush_render_backward_adam): the 52+12C bytes per splat of
 // gradients are never written to nor re-read from HBM.  v_xy is still stored (refinement statistics).
@@ -479,7 +542,12 @@ __device__ __forceinline__ void zero_invisible_rows(uint32_t n, uint32_t g0, uin
 // that owns the splat, so that v_means / v_xy / v_scales / v_quats / v_opac leave as whole cache lines, zeros and values
 // together: 1.48 vs 1.39 ms at 21 M splats, 52.2 vs 51.7 us at 1 M.  The extra barrier costs more than the partial
 // lines.)
-template <int DEG, bool ADAM>
+// PREZEROED: the compositing backward in front of this launch has already zeroed the dense arrays in passing (ZeroFill,
+// internal.hpp): only the visible splats' rows are written here, by the lanes that compute them.  (Still one lane per
+// GLOBAL id: a launch over the visible splats in depth order writes the same rows slower at every size measured — 27.5
+// vs 25.9 us at 1 M splats, 0.80 vs 0.57 ms at 21 M — because the partial lines of neighbouring splats no longer meet
+// in the L2; profiles/r04_zero_fill_in_passing.json.)
+template <int DEG, bool ADAM, bool PREZEROED = false>
 __global__ __launch_bounds__(kThreads) void k_project_backward(
     ViewParams vp, const float *means, const float *log_scales, const float *__restrict__ quats,
     const float *raw_opac, const uint32_t *__restrict__ compact_from_global,
@@ -525,7 +593,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     const uint32_t g = blockIdx.x * kThreads + li;
     const uint32_t c = threadIdx.x < nvis ? compact_from_global[g] : kInvalid;
     // Dense gradients: the zeros of the invisible splats go out first, so the stores are in flight during the VJP
-    if (!ADAM && g0 < n) zero_invisible_rows<DEG>(n, g0, lane, own_vis, v_means, v_xy, v_scales, v_quats, v_sh, v_opac);
+    if (!ADAM && !PREZEROED && g0 < n) zero_invisible_rows<DEG>(n, g0, lane, own_vis, v_means, v_xy, v_scales, v_quats, v_sh, v_opac);
 
     float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_quat[4] = {0.f, 0.f, 0.f, 0.f};
     float o_xy[2] = {0.f, 0.f}, o_opac = 0.f;
@@ -537,50 +605,10 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
     if (c != kInvalid) {
         float4 r0, r1, r2;
         load_compact_sums(v_compact, det, c, r0, r1, r2);
-        const float vxy[2] = {r0.x, r0.y};
-        const float vconic[3] = {r0.z, r0.w, r1.x};
-        vcol[0] = r1.y;
-        vcol[1] = r1.z;
-        vcol[2] = r1.w;
-        const float v_alpha_sum = r2.x;
-
-        const float mean[3] = {means[(size_t)g * 3], means[(size_t)g * 3 + 1], means[(size_t)g * 3 + 2]};
-        const float scale[3] = {det_expf(log_scales[(size_t)g * 3]), det_expf(log_scales[(size_t)g * 3 + 1]),
-                                det_expf(log_scales[(size_t)g * 3 + 2])};
-        const float4 q4 = reinterpret_cast<const float4 *>(quats)[g];
-        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-
-        // ---- GatherGrads (gather_grads.wgsl:174-231)
-        float dir[3];
-        view_dir(vp, mean, dir);
-        sh_basis<ncoef>(DEG, dir, Y);
-        const float sg = det_sigmoid(raw_opac[g]);
-        o_opac = v_alpha_sum * (sg * (1.0f - sg));
-        o_xy[0] = vxy[0];
-        o_xy[1] = vxy[1];
-
-        // ---- ProjectBackwards (project_backwards.wgsl:83-226)
-        splat_projection_vjp(vp, mean, scale, quat, vxy, vconic, o_mean, o_scale, o_quat);
-
-        if (!ADAM) {  // dense gradients: the computing lane writes the visible splat's rows itself (ordinary stores)
-            const size_t gg = g;
-            if (v_xy) reinterpret_cast<float2 *>(v_xy)[gg] = make_float2(o_xy[0], o_xy[1]);
-            reinterpret_cast<float4 *>(v_quats)[gg] = make_float4(o_quat[0], o_quat[1], o_quat[2], o_quat[3]);
-            v_opac[gg] = o_opac;
-#pragma unroll
-            for (int k = 0; k < 3; k++) v_means[gg * 3 + k] = o_mean[k], v_scales[gg * 3 + k] = o_scale[k];
-            float *row = v_sh + gg * kRow;  // v_sh row = Y[k] * v_rgb (gather_grads.wgsl:186-222)
-            if constexpr (kRow % 4 == 0) {
-#pragma unroll
-                for (uint32_t j = 0; j < kRow / 4; j++)
-                    reinterpret_cast<float4 *>(row)[j] =
-                        make_float4(Y[(4 * j) / 3] * vcol[(4 * j) % 3], Y[(4 * j + 1) / 3] * vcol[(4 * j + 1) % 3],
-                                    Y[(4 * j + 2) / 3] * vcol[(4 * j + 2) % 3], Y[(4 * j + 3) / 3] * vcol[(4 * j + 3) % 3]);
-            } else {
-#pragma unroll
-                for (uint32_t e = 0; e < kRow; e++) row[e] = Y[e / 3] * vcol[e % 3];
-            }
-        }
+        visible_splat_vjp<DEG>(vp, means, log_scales, quats, raw_opac, g, r0, r1, r2, o_mean, o_scale, o_quat, o_opac, o_xy,
+                               vcol, Y);
+        // dense gradients: the computing lane writes the visible splat's rows itself (ordinary stores)
+        if (!ADAM) store_visible_rows<DEG>(g, o_mean, o_scale, o_quat, o_opac, o_xy, vcol, Y, v_means, v_xy, v_scales, v_quats, v_sh, v_opac);
         if (ADAM) {
             float *r = res + li * kRes;  // hand the results to the lane that owns splat `li`
             r[0] = o_mean[0], r[1] = o_mean[1], r[2] = o_mean[2];
@@ -841,7 +869,7 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
                                    const float *quats, const float *raw_opac,
                                    const uint32_t *compact_from_global, const float *v_compact, float *v_means,
                                    float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
-                                   const AdamFuse *adam, const DetSumsArgs &dargs, hipStream_t s) {
+                                   const AdamFuse *adam, const DetSumsArgs &dargs, bool prezeroed, hipStream_t s) {
     const uint32_t n = vp.total_splats;
     if (n == 0) return hipSuccess;
     const dim3 grid(ceil_div(n, kThreads)), block(kThreads);
@@ -853,6 +881,10 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
         hipLaunchKernelGGL((k_project_backward<D, true>), grid, block, 0, s, vp, means, log_scales, quats,      \
                            raw_opac, compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats, v_sh,    \
                            v_opac, af, det);                                                                    \
+    else if (prezeroed)                                                                                         \
+        hipLaunchKernelGGL((k_project_backward<D, false, true>), grid, block, 0, s, vp, means, log_scales,      \
+                           quats, raw_opac, compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats,   \
+                           v_sh, v_opac, af, det);                                                              \
     else                                                                                                        \
         hipLaunchKernelGGL((k_project_backward<D, false>), grid, block, 0, s, vp, means, log_scales, quats,     \
                            raw_opac, compact_from_global, v_compact, v_means, v_xy, v_scales, v_quats, v_sh,    \

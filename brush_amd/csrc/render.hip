@@ -311,14 +311,17 @@ extern "C" uint32_t brush_rgba8_row_pitch(uint32_t width) { return (width + 63u)
 // RasterizeBackwards (render.rs:505-532): the compact-order sums of every visible splat.  Default: zero the
 // accumulators, add with hardware float atomics.  Deterministic mode: one stored row per intersection, then the
 // fixed-order per-splat sums (no zero-fill, no atomics).  Fills `det` for the consumer kernel.
+// `fill` (may be inactive): zero-fill the compositing kernel carries in passing; *filled says whether it ran.
 static int composite_backward(const BrushUniforms &u, const BrushAux &aux, const float *out_img, const float *v_out,
-                              uint32_t n, const BwdWs &ws, DetSumsArgs *det, hipStream_t s) {
+                              uint32_t n, const BwdWs &ws, DetSumsArgs *det, const ZeroFill &fill, bool *filled,
+                              hipStream_t s) {
     const uint32_t w = u.img_size[0], h = u.img_size[1], tbx = u.tile_bounds[0], tby = u.tile_bounds[1];
+    *filled = fill.active() && tbx * tby != 0u;  // (no tiles: no launch)
     if (ws.rows) {
         // no zero-fill stage in this mode: no launch, no event
         BRUSH_HIP_CHECK(launch_rasterize_backward(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
                                                   aux.projected_splats, aux.final_index, out_img, v_out, ws.v_compact,
-                                                  aux.isect_unsorted_pos, ws.rows, s));
+                                                  aux.isect_unsorted_pos, ws.rows, fill, s));
         BRUSH_HIP_CHECK(launch_sum_isect_rows(ws.rows, aux.num_intersections, aux.cum_tiles_hit, aux.max_intersects,
                                               ws.v_compact, ws.partials, s));
         mark_bwd(s, 2);
@@ -337,7 +340,7 @@ static int composite_backward(const BrushUniforms &u, const BrushAux &aux, const
     if (stop_behind(BRUSH_STAGE_BWD_ZERO)) return BRUSH_OK;
     BRUSH_HIP_CHECK(launch_rasterize_backward(w, h, tbx, tby, aux.compact_gid_from_isect, aux.tile_bins,
                                               aux.projected_splats, aux.final_index, out_img, v_out, ws.v_compact,
-                                              nullptr, nullptr, s));
+                                              nullptr, nullptr, fill, s));
     mark_bwd(s, 2);
     return BRUSH_OK;
 }
@@ -361,14 +364,24 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
     u.total_splats = n;
     const ViewParams vp = make_view_params(u, n);
 
+    // Dense gradients (render.rs:539-547,573-575 zero-fill them with launches of their own): the VALU-bound compositing
+    // kernel stores the zeros in passing, the VJP kernel behind it writes the visible splats' rows only.
+    ZeroFill fill{};
+    if (!adam && n > 0) {
+        const size_t nn = n, C = (size_t)(u.sh_degree + 1) * (u.sh_degree + 1);
+        float *const arrays[kFillSegs] = {v_sh, v_means, v_scales, v_quats, v_opac, v_xy};
+        const size_t floats[kFillSegs] = {nn * C * 3, nn * 3, nn * 3, nn * 4, nn, nn * 2};
+        (void)make_zero_fill(&fill, arrays, floats, kFillSegs);  // (unaligned / oversized arrays: zeros stay in the VJP kernel)
+    }
     mark_bwd(s, 0);
     DetSumsArgs det;
-    if (const int rc = composite_backward(u, aux, out_img, v_out, n, ws, &det, s)) return rc;
+    bool filled = false;
+    if (const int rc = composite_backward(u, aux, out_img, v_out, n, ws, &det, fill, &filled, s)) return rc;
     if (stop_behind(BRUSH_STAGE_BWD_ZERO) || stop_behind(BRUSH_STAGE_RASTERIZE_BWD)) return BRUSH_OK;
     // GatherGrads + ProjectBackwards fused, dense outputs written once (render.rs:534-594)
     BRUSH_HIP_CHECK(launch_project_backward(vp, means, log_scales, quats, raw_opacity, aux.compact_from_global_gid,
                                             ws.v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac, adam, det,
-                                            s));
+                                            filled, s));
     mark_bwd(s, 3);
     return BRUSH_OK;
 }
@@ -451,7 +464,8 @@ extern "C" int brush_render_backward_records(const BrushUniforms *h_uniforms, co
     const ViewParams vp = make_view_params(u, n);
     mark_bwd(s, 0);
     DetSumsArgs det;
-    if (const int rc = composite_backward(u, aux, out_img, v_out, n, ws, &det, s)) return rc;
+    bool filled = false;
+    if (const int rc = composite_backward(u, aux, out_img, v_out, n, ws, &det, ZeroFill{}, &filled, s)) return rc;
     BRUSH_HIP_CHECK(launch_project_backward_records(vp, means, log_scales, quats, raw_opacity, aux.num_visible,
                                                     aux.global_from_compact_gid, ws.v_compact, records, max_rows, det,
                                                     s));

@@ -469,6 +469,57 @@ def test_tiny_and_empty_inputs(dev, n):
     _assert_grad_parity(gpu, orc)
 
 
+@pytest.mark.parametrize("n,deg,w,h", [(1003, 3, 200, 120), (1001, 2, 64, 48), (70001, 0, 640, 480), (5, 4, 32, 32)])
+def test_dense_gradients_zeroed_in_passing(dev, n, deg, w, h):
+    """The compositing backward zero-fills the dense gradient arrays beside its arithmetic (ZeroFill) and the VJP kernel
+    writes the visible rows only: NaN-poisoned outputs must come back dense — exact zeros off the visible set, the same
+    bits as the all-in-one VJP kernel on it — for splat counts that leave partial KiB blocks and 1-3 trailing floats in
+    every array, in both accumulation modes; arrays that are not 16-byte aligned take the old path (zeros written by the
+    VJP kernel) and must give the same bits."""
+    import torch
+
+    import brush_amd
+    from brush_amd import render as R
+
+    cloud = H.synthetic_cloud(n, deg, seed=11, mean_mult=0.002)
+    p = {k: _t(v, dev) for k, v in cloud.items()}
+    C = (deg + 1) ** 2
+    cam = _camera(w, h)
+    rng = np.random.default_rng(3)
+    v_out = _t(rng.standard_normal((h, w, 4)).astype(np.float32) / np.float32(h * w), dev)
+    layout, total = R.grad_block_layout(n, C)
+    for det in (False, True):
+        out, aux, u = R._forward_impl(cam, (w, h), p["means"], p["log_scales"], p["quats"], p["sh"], p["raw_opac"], False,
+                                      None, deterministic=det)
+        V = aux.read_num_visible()
+        assert 0 < V
+        vis = torch.zeros(n, dtype=torch.bool, device=dev)
+        vis[aux.global_from_compact_gid[:V].long()] = True
+        runs = {}
+        for name, shift in (("aligned", 0), ("unaligned", 1)):
+            # guard floats of NaN around the block: the fill must not write outside the arrays either
+            buf = torch.full((total + 16,), float("nan"), device=dev)
+            block = buf[4 + shift:4 + shift + total]
+            assert (block.data_ptr() % 16 == 0) == (shift == 0)
+            g, _ = R._backward_impl(u, aux, p["means"], p["log_scales"], p["quats"], p["raw_opac"], C, out, v_out, block)
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(buf[:4 + shift]).all()) and bool(torch.isnan(buf[4 + shift + total:]).all())
+            for off, sz in layout.values():  # the padding between the arrays of the block stays untouched as well
+                assert bool(torch.isnan(block[off + sz:(off + sz + 3) // 4 * 4]).all())
+            for k, t in g.items():
+                assert not bool(torch.isnan(t).any()), (det, name, k)
+                assert not bool(t[~vis].any()), (det, name, k)
+            runs[name] = {k: t.clone() for k, t in g.items()}
+        if det:  # bitwise reproducible mode: the two paths must agree to the bit
+            for k in runs["aligned"]:
+                assert torch.equal(runs["aligned"][k], runs["unaligned"][k]), k
+        else:    # float atomics: the compositing sums differ in arrival order only
+            for k in runs["aligned"]:
+                a, b = runs["aligned"][k], runs["unaligned"][k]
+                assert torch.allclose(a, b, rtol=1e-3, atol=1e-6 * float(b.abs().max()) + 1e-30), k
+
+
+
 def test_walk_queue_overflow_falls_back_inline(dev):
     """A handful of whole-screen splats need far more (splat, chunk) work items than the queue
     holds (capacity = N): the overflowing splats are walked inline and the result is unchanged."""
