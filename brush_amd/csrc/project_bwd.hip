@@ -260,8 +260,8 @@ __device__ __forceinline__ float adam_elem(const AdamFuse &a, size_t e, float g,
     a.m1[e] = m, a.m2[e] = v;
     return x - ((m / a.bc1) / (sqrtf(v / a.bc2) + a.eps)) * lr;
 }
-__device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4 g, float4 x, float lr) {
-    const float4 mo = nt_load4(a.m1 + e), vo = nt_load4(a.m2 + e);
+__device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4 g, float4 x, float4 mo, float4 vo,
+                                             float lr) {
     float4 m, v, r;
 #define BRUSH_ADAM_C(c)                                                        \
     m.c = mo.c * a.beta1 + g.c * (1.0f - a.beta1);                             \
@@ -272,6 +272,9 @@ __device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4
     nt_store4(a.m1 + e, m);
     nt_store4(a.m2 + e, v);
     return r;
+}
+__device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4 g, float4 x, float lr) {
+    return adam_elem4(a, e, g, x, nt_load4(a.m1 + e), nt_load4(a.m2 + e), lr);
 }
 
 // Last phase of the backward for the 64 splats [g0, g0+64) of one wave: the lane that owns splat g0+lane holds its
@@ -345,32 +348,56 @@ __device__ __forceinline__ void store_gradients_or_step(
             }
         };
         if (((rowf & 3u) == 0 || rows == kWave) && (!ADAM || af.vec_ok)) {
-            // float4 path: rowf*64 is a multiple of 4 and the wave's base offset is 16-B aligned
-            for (uint32_t j = lane * 4; j < total; j += kWave * 4) {
-                if (j + 4 <= total) {
-                    float4 v;
-                    float *e = reinterpret_cast<float *>(&v);
+            // float4 path: rowf*64 is a multiple of 4 and the wave's base offset is 16-B aligned.  ADAM: the three
+            // streams of kUnroll chunks are requested before the first one is used — 12 KiB in flight per wave
+            // instead of 3 (the kernel runs three waves per SIMD and a request takes ~2 us under load: Little's law asks for
+            // ~10 MB in flight on the chip at 5 TB/s, one chunk at a time gave 9).
+            constexpr uint32_t kUnroll = 4;
+            auto staged4 = [&](uint32_t j) {
+                float4 v;
+                float *e = reinterpret_cast<float *>(&v);
 #pragma unroll
-                    for (uint32_t i = 0; i < 4; i++) {
-                        const uint32_t f = j + i;
-                        e[i] = stage[(f / rowf) * stride + (f % rowf)];
-                    }
-                    if (!ADAM) {
-                        nt_store4(dst + j, v);  // write-once stream
-                    } else {
-                        const float4 x = nt_load4(dst + j);
-                        float4 st = adam_elem4(af, seg + j, v, x, lr);
-                        if (is_sh) {
-                            const uint32_t k0 = j % rowf;  // position in the SH row; rows are rowf floats
-                            st.x = (k0 + 0) % rowf >= 3 ? x.x * (1.0f - af.sh_lerp) + st.x * af.sh_lerp : st.x;
-                            st.y = (k0 + 1) % rowf >= 3 ? x.y * (1.0f - af.sh_lerp) + st.y * af.sh_lerp : st.y;
-                            st.z = (k0 + 2) % rowf >= 3 ? x.z * (1.0f - af.sh_lerp) + st.z * af.sh_lerp : st.z;
-                            st.w = (k0 + 3) % rowf >= 3 ? x.w * (1.0f - af.sh_lerp) + st.w * af.sh_lerp : st.w;
+                for (uint32_t i = 0; i < 4; i++) {
+                    const uint32_t f = j + i;
+                    e[i] = stage[(f / rowf) * stride + (f % rowf)];
+                }
+                return v;
+            };
+            for (uint32_t j0 = lane * 4; j0 < total; j0 += kWave * 4 * kUnroll) {
+                float4 x[kUnroll], mo[kUnroll], vo[kUnroll];
+                if (ADAM) {
+#pragma unroll
+                    for (uint32_t u = 0; u < kUnroll; u++) {
+                        const uint32_t j = j0 + u * kWave * 4;
+                        if (j + 4 <= total) {
+                            x[u] = nt_load4(dst + j);
+                            mo[u] = nt_load4(af.m1 + seg + j);
+                            vo[u] = nt_load4(af.m2 + seg + j);
                         }
-                        nt_store4(dst + j, st);
                     }
-                } else {
-                    for (uint32_t f = j; f < total; f++) one(f);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kUnroll; u++) {
+                    const uint32_t j = j0 + u * kWave * 4;
+                    if (j + 4 <= total) {
+                        const float4 v = staged4(j);
+                        if (!ADAM) {
+                            nt_store4(dst + j, v);  // write-once stream
+                        } else {
+                            float4 st = adam_elem4(af, seg + j, v, x[u], mo[u], vo[u], lr);
+                            if (is_sh) {
+                                const uint32_t k0 = j % rowf;  // position in the SH row; rows are rowf floats
+                                const float4 xo = x[u];
+                                st.x = (k0 + 0) % rowf >= 3 ? xo.x * (1.0f - af.sh_lerp) + st.x * af.sh_lerp : st.x;
+                                st.y = (k0 + 1) % rowf >= 3 ? xo.y * (1.0f - af.sh_lerp) + st.y * af.sh_lerp : st.y;
+                                st.z = (k0 + 2) % rowf >= 3 ? xo.z * (1.0f - af.sh_lerp) + st.z * af.sh_lerp : st.z;
+                                st.w = (k0 + 3) % rowf >= 3 ? xo.w * (1.0f - af.sh_lerp) + st.w * af.sh_lerp : st.w;
+                            }
+                            nt_store4(dst + j, st);
+                        }
+                    } else if (j < total) {
+                        for (uint32_t f = j; f < total; f++) one(f);
+                    }
                 }
             }
         } else {
