@@ -33,6 +33,20 @@ class BrushUniforms(C.Structure):
     ]
 
 
+class BrushLazySh(C.Structure):
+    """Deferred Adam of the SH block (include/brush_hip.h: BrushLazySh)."""
+    _fields_ = [
+        ("table", C.c_void_p),
+        ("base", C.c_uint32),
+        ("capacity", C.c_uint32),
+        ("now", C.c_uint32),
+        ("sh_time", C.c_void_p),
+        ("sh_moment1", C.c_void_p),
+        ("sh_moment2", C.c_void_p),
+        ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float),
+    ]
+
+
 class BrushAux(C.Structure):
     """Device-pointer mirror of RenderAux (crates/brush-render/src/lib.rs:20-33)."""
     _fields_ = [
@@ -51,6 +65,7 @@ class BrushAux(C.Structure):
         ("isect_unsorted_pos", C.c_void_p),  # deterministic mode only (NULL otherwise)
         ("flags", C.c_uint32),               # AUX_* bits, per call
         ("bwd_accum", C.c_void_p),           # NULL or the backward's workspace (forward pre-zeroes its accumulators)
+        ("lazy_sh", C.POINTER(BrushLazySh)),  # NULL or the deferred-Adam state of the SH block
     ]
 
 
@@ -63,6 +78,7 @@ class BrushAdamConfig(C.Structure):
         ("time", C.c_uint32),
         ("rotation_grad_wrt_normalized", C.c_uint32),
         ("xy_stat_scale", C.c_float),  # batch_views for view-sharded steps (0 = 1)
+        ("lazy_sh", C.POINTER(BrushLazySh)),  # NULL = every SH block is stepped (fused forms only)
     ]
 
 
@@ -120,6 +136,9 @@ _SYMBOLS = [
     ("brush_reduce_view_records_adam", C.c_int,
      [_P, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(BrushAdamConfig), C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P,
       C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    ("brush_lazy_sh_flush", C.c_int, [C.POINTER(BrushLazySh), _P, C.c_uint32, C.c_uint32, _P]),
+    ("brush_lazy_sh_fill_table", C.c_int,
+     [C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _P]),
     ("brush_normalize_quats", C.c_int, [_P, _P, C.c_uint32, _P]),
     ("brush_refine_stats", C.c_int,
      [C.POINTER(BrushAux), _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),

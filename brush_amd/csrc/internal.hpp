@@ -1,6 +1,7 @@
 // internal.hpp — host-side launch functions, one group per translation unit.
 #pragma once
 #include "common.hpp"
+#include "lazy_sh.hpp"
 
 namespace brush {
 
@@ -23,7 +24,7 @@ hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, con
                                const float *quats, const float *sh, const float *raw_opac, float *proj_global,
                                uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
                                uint32_t *gids, uint32_t *bin_edges /* [num_tiles][2], zeroed here */,
-                               const WalkWs &walk, hipStream_t s);
+                               const WalkWs &walk, const LazySh &lazy /* BrushAux::lazy_sh, or off */, hipStream_t s);
 hipError_t launch_project_visible(const ViewParams &vp, const float *proj_global, const uint32_t *num_visible,
                                   uint32_t *global_from_compact, uint32_t *compact_from_global, float *projected,
                                   uint32_t *tiles_hit, const WalkWs &walk, hipStream_t s);
@@ -73,13 +74,15 @@ struct AdamFuse {
     float *means, *log_scales, *rotation, *raw_opac, *sh;  // parameters, updated in place
     float *m1, *m2;                                        // [means 3N | log_scales 3N | quats 4N | raw_opac N | sh 3CN]
     float lr[5];                                           // means, log_scales, rotation, raw_opac, sh (dc)
-    float sh_lerp, beta1, beta2, eps, bc1, bc2;
+    float sh_lerp, beta1, beta2, eps, rbc1, rbc2;          // rbc = 1 / (1 - beta^time), see adam_stepped()
     uint32_t quat_vjp, vec_ok;
     float *norm_rot_out;                                   // optional [N,4]: updated rotation / |rotation| (next forward's input)
     float *grad_2d_accum, *xy_grad_counts;                 // optional [N]: refinement statistics (train.rs:284-316)
     float half_w, half_h;
     float stat_scale;                                      // BrushAdamConfig::xy_stat_scale (0 -> 1)
+    LazySh lazy;                                           // BrushAdamConfig::lazy_sh (off: every SH block is stepped)
 };
+hipError_t launch_lazy_sh_flush(const LazySh &lazy, float *sh, uint32_t n, uint32_t row_floats, hipStream_t s);
 // Deterministic mode: where a splat's compact-order sums come from (see project_bwd.hip); partials == nullptr
 // selects the default atomic accumulators in v_compact.
 struct DetSumsArgs {
@@ -87,6 +90,10 @@ struct DetSumsArgs {
     const uint32_t *num_intersections = nullptr;
     const float *partials = nullptr;
     uint32_t cap = 0;
+};
+struct VisibleList {
+    const uint32_t *num_visible;          // [1]
+    const uint32_t *global_from_compact;  // [N], the first *num_visible valid
 };
 hipError_t launch_sum_isect_rows(const float *rows, const uint32_t *num_intersections, const uint32_t *cum_tiles_hit,
                                  uint32_t cap, float *v_compact, float *partials, hipStream_t s);
@@ -98,6 +105,7 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
                                    const AdamFuse *adam, const DetSumsArgs &det,
                                    bool prezeroed /* dense form only: the arrays are already zero (ZeroFill), the
                                    visible splats' rows alone are written */,
+                                   const VisibleList &lazy_view /* adam->lazy on: the visible splats in compact order */,
                                    hipStream_t s);
 // View-sharded data parallelism (project_bwd.hip): per-view 64-byte gradient records, their index by global id and
 // the deterministic per-splat sum over views (dense arrays, or straight into the Adam update when adam != nullptr).

@@ -21,6 +21,7 @@
 //     coalesced, instead of zero-filling and scattering.
 // All kernels are HBM-streaming (roofline: HBM).
 #include "internal.hpp"
+#include "lazy_sh.hpp"
 #include "splat_math.hpp"
 #include "trace.hpp"
 
@@ -297,7 +298,9 @@ __device__ __forceinline__ void sh_colour(const ViewParams &vp, const float mean
 // which on MI355X is bound by address-translation misses (one page per lane per array), not by
 // bandwidth or arithmetic.  The record goes to a global-id-indexed staging row of 48 bytes;
 // k_project_visible then needs ONE gather per splat.
-template <int DEG>
+// LAZY (BrushAux::lazy_sh): the SH block is under deferred Adam (lazy_sh.hpp): a visible splat's colour is evaluated
+// from its stored coefficients with the pending zero-gradient steps replayed in registers; nothing is written back.
+template <int DEG, bool LAZY = false>
 __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushUniforms u,
                                                            const float *__restrict__ means,
                                                            const float *__restrict__ log_scales,
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                                                            uint32_t *__restrict__ overflow,
                                                            uint32_t *__restrict__ tile_bins, uint32_t num_bin_words,
                                                            uint32_t *__restrict__ bin_edges,
-                                                           uint32_t *__restrict__ walk_counter) {
+                                                           uint32_t *__restrict__ walk_counter, LazySh lazy) {
     __shared__ uint32_t wave_cnt[kThreads / kWave];
     __shared__ uint32_t vis_list[kThreads / kWave][kCullPerThread * kWave];  // per wave: global ids that passed
     BRUSH_KTRACE(kTrCull, 0);
@@ -415,7 +418,14 @@ __global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushU
                 if ((bb[2] - bb[0]) != 0u && (bb[3] - bb[1]) != 0u) {  // :60
                     visible = true;
                     float rgb[3];
-                    sh_colour<DEG>(vp, mean, sh, rgb);
+                    if constexpr (LAZY) {
+                        constexpr uint32_t kRow = (DEG + 1) * (DEG + 1) * 3;
+                        float cur[kRow];
+                        lazy_current_row<kRow>(lazy, sh_coeffs, g, cur);
+                        sh_colour<DEG>(vp, mean, cur, rgb);
+                    } else {
+                        sh_colour<DEG>(vp, mean, sh, rgb);
+                    }
                     float4 *row = proj_global + (size_t)g * 3;
                     row[0] = make_float4(xy[0], xy[1], conic[0], conic[1]);
                     row[1] = make_float4(conic[2], det_sigmoid(ro), 0.0f, 0.0f);
@@ -946,23 +956,29 @@ hipError_t launch_project_cull(const ViewParams &vp, const BrushUniforms &u, con
                                uint32_t num_tiles, const float *means, const float *log_scales,
                                const float *quats, const float *sh, const float *raw_opac, float *proj_global,
                                uint32_t *key_all, uint32_t *block_counts, uint32_t *keys,
-                               uint32_t *gids, uint32_t *bin_edges, const WalkWs &walk, hipStream_t s) {
+                               uint32_t *gids, uint32_t *bin_edges, const WalkWs &walk, const LazySh &lazy,
+                               hipStream_t s) {
     const uint32_t n = vp.total_splats;
     const uint32_t blocks = (uint32_t)cull_block_count(n);
     uint32_t *compact_from_global = aux.compact_from_global_gid;
     uint32_t *num_visible = aux.num_visible;
     uint32_t *uniforms_buffer = aux.uniforms_buffer;
-#define BRUSH_LAUNCH_CULL(D)                                                                                     \
-    hipLaunchKernelGGL(k_project_cull<D>, dim3(blocks), dim3(kThreads), 0, s, vp, u, means, log_scales, quats, sh, \
-                       raw_opac, reinterpret_cast<float4 *>(proj_global), key_all, compact_from_global,          \
+#define BRUSH_LAUNCH_CULL(D, L)                                                                                  \
+    hipLaunchKernelGGL((k_project_cull<D, L>), dim3(blocks), dim3(kThreads), 0, s, vp, u, means, log_scales, quats, \
+                       sh, raw_opac, reinterpret_cast<float4 *>(proj_global), key_all, compact_from_global,      \
                        block_counts, uniforms_buffer, aux.num_intersections, aux.overflow, aux.tile_bins,        \
-                       num_tiles * 2, bin_edges, walk.counter)
-    switch (vp.sh_degree) {
-        case 0: BRUSH_LAUNCH_CULL(0); break;
-        case 1: BRUSH_LAUNCH_CULL(1); break;
-        case 2: BRUSH_LAUNCH_CULL(2); break;
-        case 3: BRUSH_LAUNCH_CULL(3); break;
-        default: BRUSH_LAUNCH_CULL(4); break;
+                       num_tiles * 2, bin_edges, walk.counter, lazy)
+    if (lazy.on()) {  // rows of whole 16-byte chunks only (make_lazy_sh)
+        if (vp.sh_degree == 1) BRUSH_LAUNCH_CULL(1, true);
+        else BRUSH_LAUNCH_CULL(3, true);
+    } else {
+        switch (vp.sh_degree) {
+            case 0: BRUSH_LAUNCH_CULL(0, false); break;
+            case 1: BRUSH_LAUNCH_CULL(1, false); break;
+            case 2: BRUSH_LAUNCH_CULL(2, false); break;
+            case 3: BRUSH_LAUNCH_CULL(3, false); break;
+            default: BRUSH_LAUNCH_CULL(4, false); break;
+        }
     }
 #undef BRUSH_LAUNCH_CULL
     if (blocks <= kSelfScanBlocks) {

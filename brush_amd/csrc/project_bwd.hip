@@ -29,6 +29,7 @@ namespace brush {
 namespace {
 
 constexpr uint32_t kThreads = 256;
+constexpr uint32_t kRecFloats = 16;  // floats per per-view gradient record (k_project_backward_records)
 
 // project_backwards.wgsl:25-57; G(a,b) = WGSL v_R[a][b] = column a, row b.
 __device__ __forceinline__ void quat_to_rotmat_vjp(const float q[4], const Mat3 &vR, float o[4]) {
@@ -258,7 +259,7 @@ __device__ __forceinline__ float adam_elem(const AdamFuse &a, size_t e, float g,
     const float m = a.m1[e] * a.beta1 + g * (1.0f - a.beta1);
     const float v = a.m2[e] * a.beta2 + (g * g) * (1.0f - a.beta2);
     a.m1[e] = m, a.m2[e] = v;
-    return x - ((m / a.bc1) / (sqrtf(v / a.bc2) + a.eps)) * lr;
+    return adam_stepped(m, v, x, a.rbc1, a.rbc2, a.eps, lr);
 }
 __device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4 g, float4 x, float4 mo, float4 vo,
                                              float lr) {
@@ -266,7 +267,7 @@ __device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4
 #define BRUSH_ADAM_C(c)                                                        \
     m.c = mo.c * a.beta1 + g.c * (1.0f - a.beta1);                             \
     v.c = vo.c * a.beta2 + (g.c * g.c) * (1.0f - a.beta2);                     \
-    r.c = x.c - ((m.c / a.bc1) / (sqrtf(v.c / a.bc2) + a.eps)) * lr;
+    r.c = adam_stepped(m.c, v.c, x.c, a.rbc1, a.rbc2, a.eps, lr);
     BRUSH_ADAM_C(x) BRUSH_ADAM_C(y) BRUSH_ADAM_C(z) BRUSH_ADAM_C(w)
 #undef BRUSH_ADAM_C
     nt_store4(a.m1 + e, m);
@@ -672,6 +673,159 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
                                               v_sh, v_opac);
 }
 
+// ---- fused backward + Adam with the SH block under deferred Adam (BrushAdamConfig::lazy_sh) ---------------------------
+// With the SH block out of the stream the all-in-one kernel above is a chain of small dependent memory phases per wave
+// (measured: 155 us at 1 M splats for 0.4 GB).  Two launches instead:
+//   k_project_backward_lazy<DEG>  one lane per VISIBLE splat, compact order: the projection VJP, its 64-byte record
+//       (the layout of k_project_backward_records) written over the splat's own accumulator row, v_xy[g], and the splat's
+//       SH block: pending zero-gradient steps replayed, this step applied, sh_time advanced.
+//   k_adam_small_groups           one lane per splat, a plain stream over the 11 floats of means / log_scales / rotation /
+//       raw_opacity and their moments; a visible splat's gradient is its record.
+// Same expressions as store_gradients_or_step<ADAM>: the same bits as the all-in-one kernel.
+constexpr uint32_t kLazyThreads = kWave;  // one wave per workgroup: ~1600 waves of work at 1 M splats spread over every SIMD
+template <int DEG>
+__global__ __launch_bounds__(kLazyThreads) void k_project_backward_lazy(
+    ViewParams vp, const float *means, const float *log_scales, const float *__restrict__ quats, const float *raw_opac,
+    const uint32_t *__restrict__ num_visible, const uint32_t *__restrict__ global_from_compact, float *v_compact,
+    float *__restrict__ v_xy, AdamFuse af, DetSums det) {
+    constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1), kRow = ncoef * 3, kChunks = kRow / 4;
+    static_assert(kRow % 4 == 0, "rows of whole 16-byte chunks");
+    // per wave: what the 64 splats' SH rows need - global id, the time the stored block is current for, v_rgb, Y
+    constexpr uint32_t kFac = 5 + ncoef;
+    __shared__ float fac_all[kLazyThreads / kWave][kWave][kFac | 1u];
+    const uint32_t wv = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    float(*fac)[kFac | 1u] = fac_all[wv];
+    const uint32_t n = vp.total_splats, V = min(*num_visible, n);
+    const size_t nn = n;
+    const uint32_t waves = gridDim.x * (kLazyThreads / kWave);
+    for (uint32_t c0 = (blockIdx.x * (kLazyThreads / kWave) + wv) * kWave; c0 < V; c0 += waves * kWave) {  // wave-uniform
+        const uint32_t c = c0 + lane;
+        uint32_t g = kInvalid;
+        if (c < V) {
+            g = global_from_compact[c];
+            float4 r0, r1, r2;
+            load_compact_sums(v_compact, det, c, r0, r1, r2);
+            float o_mean[3], o_scale[3], o_quat[4], o_xy[2], o_opac, vcol[3], Y[ncoef];
+            visible_splat_vjp<DEG>(vp, means, log_scales, quats, raw_opac, g, r0, r1, r2, o_mean, o_scale, o_quat, o_opac,
+                                   o_xy, vcol, Y);
+            const float vx = o_xy[0] * af.half_w, vy = o_xy[1] * af.half_h;  // train.rs:300-302
+            float4 *out = reinterpret_cast<float4 *>(v_compact) + (size_t)c * kCompactVec;
+            out[0] = make_float4(__uint_as_float(g), o_mean[0], o_mean[1], o_mean[2]);
+            out[1] = make_float4(o_scale[0], o_scale[1], o_scale[2], o_quat[0]);
+            out[2] = make_float4(o_quat[1], o_quat[2], o_quat[3], o_opac);
+            out[3] = make_float4(vcol[0], vcol[1], vcol[2], sqrtf(vx * vx + vy * vy));
+            reinterpret_cast<float2 *>(v_xy)[g] = make_float2(o_xy[0], o_xy[1]);
+            fac[lane][1] = __uint_as_float(af.lazy.sh_time[g]);
+            fac[lane][2] = vcol[0], fac[lane][3] = vcol[1], fac[lane][4] = vcol[2];
+#pragma unroll
+            for (uint32_t k = 0; k < ncoef; k++) fac[lane][5 + k] = Y[k];
+        }
+        fac[lane][0] = __uint_as_float(g);
+        __builtin_amdgcn_wave_barrier();
+        // The 64 SH blocks of the wave, kChunks consecutive lanes per row (whole lines per request); the three streams of
+        // up to six chunks per lane are requested together (the registers of the VJP are free again by now; all twelve of
+        // a degree-3 row need 479).  Catch up, then this step (gradient row = Y[k] * v_rgb, gather_grads.wgsl:186-222).
+        constexpr uint32_t kBatch = kChunks <= 6 ? kChunks : 6;
+        static_assert(kChunks % kBatch == 0, "whole batches");
+        for (uint32_t it0 = 0; it0 < kChunks; it0 += kBatch) {
+            float4 x[kBatch], mo[kBatch], vo[kBatch];
+            uint32_t gr_[kBatch];
+#pragma unroll
+            for (uint32_t u = 0; u < kBatch; u++) {
+                const uint32_t q = (it0 + u) * kWave + lane, r = q / kChunks, j = q - r * kChunks;
+                gr_[u] = __float_as_uint(fac[r][0]);
+                if (gr_[u] != kInvalid) {
+                    const size_t e = (size_t)gr_[u] * kRow + 4 * j;
+                    x[u] = *reinterpret_cast<const float4 *>(af.sh + e);
+                    mo[u] = *reinterpret_cast<const float4 *>(af.m1 + 11 * nn + e);
+                    vo[u] = *reinterpret_cast<const float4 *>(af.m2 + 11 * nn + e);
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kBatch; u++) {
+                if (gr_[u] == kInvalid) continue;
+                const uint32_t q = (it0 + u) * kWave + lane, r = q / kChunks, j = q - r * kChunks;
+                const size_t e = (size_t)gr_[u] * kRow + 4 * j;
+                lazy_replay4(af.lazy, __float_as_uint(fac[r][1]), 4 * j, mo[u], vo[u], x[u]);
+                const uint32_t k0 = 4 * j;
+                const float4 gr = make_float4(fac[r][5 + (k0 + 0) / 3] * fac[r][2 + (k0 + 0) % 3],
+                                              fac[r][5 + (k0 + 1) / 3] * fac[r][2 + (k0 + 1) % 3],
+                                              fac[r][5 + (k0 + 2) / 3] * fac[r][2 + (k0 + 2) % 3],
+                                              fac[r][5 + (k0 + 3) / 3] * fac[r][2 + (k0 + 3) % 3]);
+                float4 st = adam_elem4(af, 11 * nn + e, gr, x[u], mo[u], vo[u], af.lr[4]);
+                st.x = k0 + 0 >= 3 ? x[u].x * (1.0f - af.sh_lerp) + st.x * af.sh_lerp : st.x;
+                st.y = k0 + 1 >= 3 ? x[u].y * (1.0f - af.sh_lerp) + st.y * af.sh_lerp : st.y;
+                st.z = k0 + 2 >= 3 ? x[u].z * (1.0f - af.sh_lerp) + st.z * af.sh_lerp : st.z;
+                st.w = k0 + 3 >= 3 ? x[u].w * (1.0f - af.sh_lerp) + st.w * af.sh_lerp : st.w;
+                *reinterpret_cast<float4 *>(af.sh + e) = st;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the rows are read; the next round of the wave may overwrite them
+        if (g != kInvalid) af.lazy.sh_time[g] = af.lazy.now + 1u;
+    }
+}
+
+// One lane per 16-byte chunk of the small-group parameter space [means 3N | log_scales 3N | rotation 4N | raw_opacity N]
+// (the layout of the moment arrays): three streaming loads, three streaming stores, nothing else resident.  A chunk of
+// means / log_scales spans two splats, a chunk of raw_opacity four: each element looks its splat up (neighbouring lanes
+// share the words) and a visible splat's gradient is a field of its record.  The rotation chunks (one splat each) also
+// carry the per-splat duties: chain rule through the normalisation, next_quats_fed, the refinement statistics, and the
+// zero v_xy of a splat the view does not see.  Requires n % 4 == 0 and 16-byte aligned arrays (AdamFuse::vec_ok).
+__global__ __launch_bounds__(kThreads) void k_adam_small_groups(AdamFuse af, uint32_t n,
+                                                                const uint32_t *__restrict__ compact_from_global,
+                                                                const float *__restrict__ records,
+                                                                float *__restrict__ v_xy) {
+    const size_t nn = n;
+    const size_t e0 = ((size_t)blockIdx.x * kThreads + threadIdx.x) * 4;  // first float of the chunk in moment order
+    if (e0 >= 11 * nn) return;
+    float *p;
+    size_t rel;
+    float lr;
+    uint32_t rowf, field0;  // floats per splat in this segment; record word of its first component
+    if (e0 < 3 * nn) p = af.means, rel = e0, lr = af.lr[0], rowf = 3, field0 = 1;
+    else if (e0 < 6 * nn) p = af.log_scales, rel = e0 - 3 * nn, lr = af.lr[1], rowf = 3, field0 = 4;
+    else if (e0 < 10 * nn) p = af.rotation, rel = e0 - 6 * nn, lr = af.lr[2], rowf = 4, field0 = 7;
+    else p = af.raw_opac, rel = e0 - 10 * nn, lr = af.lr[3], rowf = 1, field0 = 11;
+    float4 x = nt_load4(p + rel);
+    const float4 mo = nt_load4(af.m1 + e0), vo = nt_load4(af.m2 + e0);
+    float gr[4];
+    uint32_t c_first = kInvalid;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t gi = (uint32_t)((rel + i) / rowf), comp = (uint32_t)((rel + i) - (size_t)gi * rowf);
+        const uint32_t c = compact_from_global[gi];
+        if (i == 0) c_first = c;
+        gr[i] = c != kInvalid ? records[(size_t)c * kRecFloats + field0 + comp] : 0.0f;
+    }
+    float4 g4 = make_float4(gr[0], gr[1], gr[2], gr[3]);
+    if (rowf == 4) {  // one splat per chunk: the per-splat duties ride here
+        const uint32_t g = (uint32_t)(rel / 4);
+        const bool vis = c_first != kInvalid;
+        if (af.quat_vjp) {  // the op was fed rot/|rot| (gaussian_splats.rs:174-175); chain v_q to the raw parameter
+            const float s2 = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+            const float inv_s = 1.0f / sqrtf(s2);
+            const float dot = (g4.x * x.x + g4.y * x.y + g4.z * x.z + g4.w * x.w) * (inv_s * inv_s * inv_s);
+            g4 = make_float4(g4.x * inv_s - x.x * dot, g4.y * inv_s - x.y * dot, g4.z * inv_s - x.z * dot,
+                             g4.w * inv_s - x.w * dot);
+        }
+        if (af.grad_2d_accum) {  // train.rs:284-316
+            const float stat_norm = vis ? records[(size_t)c_first * kRecFloats + 15] : 0.0f;
+            af.grad_2d_accum[g] += stat_norm * af.stat_scale;
+            if (vis) af.xy_grad_counts[g] += 1.0f;
+        }
+        if (!vis) reinterpret_cast<float2 *>(v_xy)[g] = make_float2(0.f, 0.f);  // (visible: k_project_backward_lazy)
+        x = adam_elem4(af, e0, g4, x, mo, vo, lr);
+        nt_store4(p + rel, x);
+        if (af.norm_rot_out) {  // what the next forward will be fed (gaussian_splats.rs:174-175)
+            const float s = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
+            reinterpret_cast<float4 *>(af.norm_rot_out)[g] = make_float4(x.x / s, x.y / s, x.z / s, x.w / s);
+        }
+        return;
+    }
+    x = adam_elem4(af, e0, g4, x, mo, vo, lr);
+    nt_store4(p + rel, x);
+}
+
 // ---- view-sharded data parallelism: per-view gradient records and their deterministic reduction ------------
 //
 // A view's parameter gradient is non-zero only for its visible splats and its SH row is rank one,
@@ -683,7 +837,6 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
 // No atomics: the sum is the same bit pattern on every rank and from run to run, so replicated parameters stay
 // replicated.  The sums go through store_gradients_or_step: dense arrays, or straight into the Adam update.
 
-constexpr uint32_t kRecFloats = 16;
 
 __global__ __launch_bounds__(kThreads) void k_project_backward_records(
     ViewParams vp, const float *__restrict__ means, const float *__restrict__ log_scales,
@@ -883,7 +1036,37 @@ __global__ __launch_bounds__(kThreads) void k_reduce_view_records_dense(
     }
 }
 
+// brush_lazy_sh_flush: one lane per 16-byte chunk of the SH block; a chunk behind lazy.now replays its pending steps.
+// sh_time is only read here (all chunks of a row read the same word); the launcher sets it to `now` afterwards.
+__global__ __launch_bounds__(kThreads) void k_lazy_sh_flush(LazySh lazy, float *__restrict__ sh, uint32_t chunks_per_row,
+                                                            uint64_t total_chunks) {
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total_chunks) return;
+    const uint32_t g = (uint32_t)(i / chunks_per_row), k0 = (uint32_t)(i - (uint64_t)g * chunks_per_row) * 4u;
+    const uint32_t t0 = lazy.sh_time[g];
+    if (t0 >= lazy.now) return;
+    float4 x = nt_load4(sh + i * 4), m = nt_load4(lazy.m1 + i * 4), v = nt_load4(lazy.m2 + i * 4);
+    lazy_replay4(lazy, t0, k0, m, v, x);
+    nt_store4(sh + i * 4, x);
+    nt_store4(lazy.m1 + i * 4, m);
+    nt_store4(lazy.m2 + i * 4, v);
+}
+__global__ __launch_bounds__(kThreads) void k_fill_u32(uint32_t *__restrict__ dst, uint32_t value, uint32_t n) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
 }  // namespace
+
+hipError_t launch_lazy_sh_flush(const LazySh &lazy, float *sh, uint32_t n, uint32_t row_floats, hipStream_t s) {
+    const uint64_t chunks = (uint64_t)n * (row_floats / 4u);
+    if (chunks == 0) return hipSuccess;
+    if (chunks / kThreads >= 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lazy_sh_flush, dim3((uint32_t)((chunks + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, lazy, sh,
+                       row_floats / 4u, chunks);
+    hipLaunchKernelGGL(k_fill_u32, dim3(ceil_div(n, kThreads)), dim3(kThreads), 0, s, lazy.sh_time, lazy.now, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_zero_compact_grads(const uint32_t *num_visible, uint32_t n, float *v_compact, hipStream_t s) {
     const uint32_t grid = max(1u, min(ceil_div(n * 3u, kThreads), 1024u));
@@ -896,13 +1079,27 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
                                    const float *quats, const float *raw_opac,
                                    const uint32_t *compact_from_global, const float *v_compact, float *v_means,
                                    float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
-                                   const AdamFuse *adam, const DetSumsArgs &dargs, bool prezeroed, hipStream_t s) {
+                                   const AdamFuse *adam, const DetSumsArgs &dargs, bool prezeroed,
+                                   const VisibleList &lazy_view, hipStream_t s) {
     const uint32_t n = vp.total_splats;
     if (n == 0) return hipSuccess;
     const dim3 grid(ceil_div(n, kThreads)), block(kThreads);
     AdamFuse af{};
     if (adam) af = *adam;
     const DetSums det{dargs.cum_tiles_hit, dargs.num_intersections, dargs.partials, dargs.cap};
+    if (adam && af.lazy.on()) {  // SH block under deferred Adam: visible-splat kernel + small-group stream
+        const dim3 gv(min(ceil_div(n, kLazyThreads), 16384u)), bv(kLazyThreads);
+        float *vc = const_cast<float *>(v_compact);  // the records go over the accumulator rows, each lane its own
+        if (vp.sh_degree == 1)
+            hipLaunchKernelGGL(k_project_backward_lazy<1>, gv, bv, 0, s, vp, means, log_scales, quats, raw_opac,
+                               lazy_view.num_visible, lazy_view.global_from_compact, vc, v_xy, af, det);
+        else
+            hipLaunchKernelGGL(k_project_backward_lazy<3>, gv, bv, 0, s, vp, means, log_scales, quats, raw_opac,
+                               lazy_view.num_visible, lazy_view.global_from_compact, vc, v_xy, af, det);
+        hipLaunchKernelGGL(k_adam_small_groups, dim3((uint32_t)(((size_t)n * 11 / 4 + kThreads - 1) / kThreads)), block, 0,
+                           s, af, n, compact_from_global, vc, v_xy);
+        return hipGetLastError();
+    }
 #define BRUSH_LAUNCH_PB(D)                                                                                      \
     if (adam)                                                                                                   \
         hipLaunchKernelGGL((k_project_backward<D, true>), grid, block, 0, s, vp, means, log_scales, quats,      \

@@ -226,12 +226,14 @@ static int render_forward_impl(const BrushUniforms *h_uniforms, const float *mea
     const uint32_t tbx = u.tile_bounds[0], tby = u.tile_bounds[1];
     const uint32_t num_tiles = tbx * tby;
 
+    LazySh lazy;  // deferred Adam of the SH block (BrushAux::lazy_sh): colours from the caught-up coefficients
+    if (!make_lazy_sh(aux.lazy_sh, u.sh_degree, &lazy)) return BRUSH_ERR_INVALID_ARG;
     mark_fwd(s, 0);
     // uniforms buffer, counters, tile_bins = 0; ProjectSplats + order-preserving compaction
     // (render.rs:102-142)
     BRUSH_HIP_CHECK(launch_project_cull(vp, u, aux, num_tiles, means, log_scales, quats, sh_coeffs, raw_opacity,
                                         ws.proj_global, ws.key_all, ws.block_counts, ws.pre_keys, ws.pre_gids,
-                                        ws.bin_edges, ws.walk, s));
+                                        ws.bin_edges, ws.walk, lazy, s));
     mark_fwd(s, 1 + BRUSH_STAGE_PROJECT_CULL);
     if (stop_behind(BRUSH_STAGE_PROJECT_CULL)) return BRUSH_OK;
     // DepthSort: keys = f32 depth bits, all 32 bits (render.rs:151-156)
@@ -381,8 +383,26 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
     // GatherGrads + ProjectBackwards fused, dense outputs written once (render.rs:534-594)
     BRUSH_HIP_CHECK(launch_project_backward(vp, means, log_scales, quats, raw_opacity, aux.compact_from_global_gid,
                                             ws.v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac, adam, det,
-                                            filled, s));
+                                            filled, VisibleList{aux.num_visible, aux.global_from_compact_gid}, s));
     mark_bwd(s, 3);
+    return BRUSH_OK;
+}
+
+// burn 0.16 Adam::step divides by 1 - beta^time (f32); the kernels multiply by the reciprocals (adam_stepped()).  One
+// function for the eager fused step and for the table of deferred steps.
+static void adam_bias_corrections(float beta1, float beta2, uint32_t time, float *rbc1, float *rbc2) {
+    *rbc1 = 1.0f / (1.0f - powf(beta1, (float)time));
+    *rbc2 = 1.0f / (1.0f - powf(beta2, (float)time));
+}
+
+extern "C" int brush_lazy_sh_fill_table(float beta1, float beta2, float lr_coeffs_dc, float sh_rest_lerp, uint32_t base,
+                                        uint32_t capacity, float *host_rows) {
+    if (!host_rows || base > 0xFFFFFFFFu - capacity) return BRUSH_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < capacity; i++) {
+        adam_bias_corrections(beta1, beta2, base + 1u + i, &host_rows[4 * i], &host_rows[4 * i + 1]);
+        host_rows[4 * i + 2] = lr_coeffs_dc;
+        host_rows[4 * i + 3] = sh_rest_lerp;
+    }
     return BRUSH_OK;
 }
 
@@ -390,7 +410,7 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
 static bool fill_adam_fuse(const BrushAdamConfig *cfg, float *means, float *log_scales, float *rotation,
                            float *raw_opacity, float *sh, uint32_t n, float *moment1, float *moment2,
                            float *next_quats_fed, float *grad_2d_accum, float *xy_grad_counts, uint32_t w, uint32_t h,
-                           AdamFuse *out) {
+                           uint32_t sh_degree, AdamFuse *out) {
     if (!cfg || cfg->time == 0) return false;
     if (n > 0 && (!means || !log_scales || !rotation || !raw_opacity || !sh || !moment1 || !moment2)) return false;
     auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -402,8 +422,7 @@ static bool fill_adam_fuse(const BrushAdamConfig *cfg, float *means, float *log_
     af.lr[0] = cfg->lr_mean, af.lr[1] = cfg->lr_scale, af.lr[2] = cfg->lr_rotation, af.lr[3] = cfg->lr_opac;
     af.lr[4] = cfg->lr_coeffs_dc;
     af.sh_lerp = cfg->sh_rest_lerp, af.beta1 = cfg->beta1, af.beta2 = cfg->beta2, af.eps = cfg->epsilon;
-    af.bc1 = 1.0f - powf(cfg->beta1, (float)cfg->time);
-    af.bc2 = 1.0f - powf(cfg->beta2, (float)cfg->time);
+    adam_bias_corrections(cfg->beta1, cfg->beta2, cfg->time, &af.rbc1, &af.rbc2);
     af.quat_vjp = cfg->rotation_grad_wrt_normalized;
     af.norm_rot_out = next_quats_fed;
     af.grad_2d_accum = grad_2d_accum, af.xy_grad_counts = xy_grad_counts;
@@ -411,6 +430,13 @@ static bool fill_adam_fuse(const BrushAdamConfig *cfg, float *means, float *log_
     af.stat_scale = cfg->xy_stat_scale > 0.0f ? cfg->xy_stat_scale : 1.0f;
     af.vec_ok = (n % 4 == 0) && aligned(means) && aligned(log_scales) && aligned(sh) && aligned(moment1) &&
                 aligned(moment2);
+    if (cfg->lazy_sh) {
+        // deferred Adam of the SH block: this step is optimizer time now + 1, the SH segments are the tails of the
+        // moment arrays, and the chunked (16-byte) path must be the one that runs
+        if (!make_lazy_sh(cfg->lazy_sh, sh_degree, &af.lazy) || !af.vec_ok || cfg->lazy_sh->now + 1u != cfg->time ||
+            cfg->lazy_sh->sh_moment1 != moment1 + (size_t)11 * n || cfg->lazy_sh->sh_moment2 != moment2 + (size_t)11 * n)
+            return false;
+    }
     *out = af;
     return true;
 }
@@ -435,7 +461,8 @@ extern "C" int brush_render_backward_adam(const BrushUniforms *h_uniforms, const
     if ((reinterpret_cast<uintptr_t>(quats_fed) & 15) != 0) return BRUSH_ERR_INVALID_ARG;
     AdamFuse af{};
     if (!fill_adam_fuse(cfg, means, log_scales, rotation, raw_opacity, sh, n, moment1, moment2, next_quats_fed,
-                        grad_2d_accum, xy_grad_counts, h_uniforms->img_size[0], h_uniforms->img_size[1], &af))
+                        grad_2d_accum, xy_grad_counts, h_uniforms->img_size[0], h_uniforms->img_size[1],
+                        h_uniforms->sh_degree, &af))
         return BRUSH_ERR_INVALID_ARG;
     return render_backward_impl(h_uniforms, h_aux, means, log_scales, quats_fed, raw_opacity, n, out_img, v_out,
                                 nullptr, v_xy, nullptr, nullptr, nullptr, nullptr, &af, workspace, workspace_bytes,
@@ -517,11 +544,23 @@ extern "C" int brush_reduce_view_records_adam(const float *records, uint32_t num
                                               void *view_index, size_t view_index_bytes, brush_stream_t stream) {
     AdamFuse af{};
     if (!fill_adam_fuse(cfg, means, log_scales, rotation, raw_opacity, sh, n, moment1, moment2, next_quats_fed,
-                        grad_2d_accum, xy_grad_counts, width, height, &af))
+                        grad_2d_accum, xy_grad_counts, width, height, sh_degree, &af) ||
+        af.lazy.on())  // (the data-parallel reduction steps every block eagerly)
         return BRUSH_ERR_INVALID_ARG;
     return reduce_views_impl(records, num_views, rows_per_view, view_rows, view_offsets, campos, means, n, sh_degree,
                              nullptr, nullptr,
                              nullptr, nullptr, nullptr, &af, view_index, view_index_bytes, stream);
+}
+
+extern "C" int brush_lazy_sh_flush(const BrushLazySh *h_lazy, float *sh, uint32_t n, uint32_t sh_degree,
+                                   brush_stream_t stream) {
+    LazySh lazy;
+    if (!h_lazy || sh_degree > 4 || !make_lazy_sh(h_lazy, sh_degree, &lazy)) return BRUSH_ERR_INVALID_ARG;
+    if (n == 0) return BRUSH_OK;
+    if (!sh || (reinterpret_cast<uintptr_t>(sh) & 15) != 0) return BRUSH_ERR_INVALID_ARG;
+    BRUSH_HIP_CHECK(launch_lazy_sh_flush(lazy, sh, n, 3u * (sh_degree + 1u) * (sh_degree + 1u),
+                                         static_cast<hipStream_t>(stream)));
+    return BRUSH_OK;
 }
 
 #ifdef BRUSH_TRACE

@@ -21,6 +21,14 @@ class Splats(torch.nn.Module):
         # carries the screen-space xy gradient (gaussian_splats.rs:157)
         self.xys_dummy = torch.zeros((means.shape[0], 2), dtype=torch.float32, device=means.device,
                                      requires_grad=True)
+        # a SplatTrainer with deferred Adam of the SH block registers itself here; sync() applies what is pending
+        self.lazy_sh_owner = None
+
+    def sync(self):
+        """Brings sh_coeffs up to date when a trainer defers their optimizer steps (SplatTrainer.sync); readers that
+        bypass the trainer call this first (render and to_ply below do)."""
+        if self.lazy_sh_owner is not None:
+            self.lazy_sh_owner.sync(self)
 
     @classmethod
     def from_safetensors(cls, path_or_dict, device):
@@ -57,6 +65,7 @@ class Splats(torch.nn.Module):
         """crates/brush-dataset/src/splat_export.rs:67-105"""
         from .ply import splat_to_ply
 
+        self.sync()
         c = lambda p: p.detach().cpu().numpy()
         return splat_to_ply(c(self.means), c(self.log_scales), c(self.rotation), c(self.raw_opacity), c(self.sh_coeffs))
 
@@ -65,6 +74,7 @@ class Splats(torch.nn.Module):
 
     def render(self, camera: Camera, img_size, render_u32_buffer: bool = False, max_intersects=None):
         """gaussian_splats.rs:167-188"""
+        self.sync()
         rot = self.rotation
         norm_rot = rot / torch.sqrt(torch.sum(rot * rot, dim=1, keepdim=True))
         return render_splats(camera, img_size, self.means, self.xys_dummy, self.log_scales, norm_rot,

@@ -79,6 +79,8 @@ class RenderAux:
     # accumulator rows (BrushAux::bwd_accum); `bwd_ws_zeroed` is consumed by the first backward of this render
     bwd_ws: Optional[torch.Tensor] = None
     bwd_ws_zeroed: bool = False
+    # deferred Adam of the SH block (a _lib.BrushLazySh the trainer owns; None: the coefficients are current)
+    lazy_sh: Optional[object] = None
 
     @property
     def deterministic(self) -> bool:
@@ -120,6 +122,8 @@ class RenderAux:
         s.isect_unsorted_pos = None if self.isect_unsorted_pos is None else self.isect_unsorted_pos.data_ptr()
         s.flags = int(self.flags)
         s.bwd_accum = None if self.bwd_ws is None else self.bwd_ws.data_ptr()
+        if self.lazy_sh is not None:
+            s.lazy_sh = C.pointer(self.lazy_sh)
         return s
 
 
@@ -160,9 +164,11 @@ def _check_inputs(means, xy_dummy, log_scales, quats, sh_coeffs, raw_opacity):
 
 def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, raw_opacity, render_u32: bool,
                   max_intersects: Optional[int], row_pitch: Optional[int] = None,
-                  deterministic: Optional[bool] = None, expect_backward: Optional[bool] = None):
+                  deterministic: Optional[bool] = None, expect_backward: Optional[bool] = None, lazy_sh=None):
     """expect_backward (default: a float image in default mode): allocate the backward's workspace now and let the
-    forward zero its accumulator rows, so that the backward of this render needs no zero-fill launch."""
+    forward zero its accumulator rows, so that the backward of this render needs no zero-fill launch.
+    lazy_sh: a _lib.BrushLazySh (SplatTrainer's deferred Adam of the SH block): colours come from the coefficients
+    with their pending optimizer steps replayed; `sh_coeffs` is not written."""
     l = _lib.lib()
     det = deterministic_default() if deterministic is None else bool(deterministic)
     n = means.shape[0]
@@ -190,6 +196,7 @@ def _forward_impl(cam: Camera, img_size, means, log_scales, quats, sh_coeffs, ra
         max_intersects=cap,
         isect_unsorted_pos=_empty((cap,), i32, dev) if det else None,
         flags=_lib.AUX_DETERMINISTIC if det else 0,
+        lazy_sh=lazy_sh,
     )
     if row_pitch is not None:
         if not render_u32 or row_pitch < w:

@@ -50,6 +50,10 @@ class TrainConfig:
     densify_grad_thresh: float = 0.0002
     densify_size_thresh: float = 0.005
     seed: int = 42
+    # Build extension (not in the reference): deferred Adam of the SH block (include/brush_hip.h: BrushLazySh).  Same
+    # parameter values as the eager optimizer, bit for bit; SplatTrainer.sync() brings `splats.sh_coeffs` up to date
+    # for readers that do not go through the trainer (Splats.render / to_ply call it themselves).
+    deferred_sh_adam: bool = True
 
 
 @dataclass
@@ -118,6 +122,11 @@ class SplatTrainer:
         self.last_refine: Optional[RefineStats] = None
         self.rng = torch.Generator(device=dev)
         self.rng.manual_seed(self.config.seed)
+        # deferred Adam of the SH block: per-splat optimizer time of the stored block, table of per-step constants
+        self._lazy: Optional[_lib.BrushLazySh] = None
+        self._lazy_bufs = None      # (sh_time, table) tensors the struct points into
+        self._lazy_pending = False  # some block may be behind opt_time
+        splats.lazy_sh_owner = self
 
     def invalidate_cached_rotation(self):
         """Call after writing `splats.rotation` behind autograd's back (`.data.copy_(ckpt)`, an external
@@ -125,8 +134,56 @@ class SplatTrainer:
         Parameter itself, replacing the Parameter and refine_splats are detected without it."""
         self._norm_rot, self._norm_rot_key, self._norm_rot_owner = None, None, None
 
+    LAZY_TABLE_ROWS = 2048
+
+    def _lazy_state(self, splats: Splats, n: int, ncoef: int) -> Optional[_lib.BrushLazySh]:
+        """The BrushLazySh of this step (optimizer time self.opt_time), or None when the SH block is stepped eagerly:
+        rows of whole 16-byte chunks only (SH degree 1 or 3), n a multiple of 4."""
+        c = self.config
+        if not c.deferred_sh_adam or (3 * ncoef) % 4 != 0 or n % 4 != 0 or n == 0:
+            return None
+        dev = splats.means.device
+        if self._lazy is not None and self.opt_time + 1 > self._lazy.base + self._lazy.capacity:
+            self.sync(splats)   # the table ends here: bring every block to opt_time, then start a new table
+            self._lazy = None
+        if self._lazy is None:
+            import numpy as np
+            rows = np.empty((self.LAZY_TABLE_ROWS, 4), dtype=np.float32)
+            _lib.check(_lib.lib().brush_lazy_sh_fill_table(0.9, 0.999, c.lr_coeffs_dc, 1.0 / c.lr_coeffs_sh_scale,
+                                                           self.opt_time, self.LAZY_TABLE_ROWS, rows.ctypes.data),
+                       "brush_lazy_sh_fill_table")
+            table = torch.from_numpy(rows).to(dev)
+            sh_time = torch.full((n,), self.opt_time, dtype=torch.int32, device=dev)
+            z = _lib.BrushLazySh()
+            z.table, z.base, z.capacity = table.data_ptr(), self.opt_time, self.LAZY_TABLE_ROWS
+            z.sh_time = sh_time.data_ptr()
+            z.beta1, z.beta2, z.epsilon = 0.9, 0.999, 1e-15
+            self._lazy, self._lazy_bufs = z, (sh_time, table)
+        z = self._lazy
+        z.now = self.opt_time
+        z.sh_moment1 = self.moment1.data_ptr() + 4 * 11 * n
+        z.sh_moment2 = self.moment2.data_ptr() + 4 * 11 * n
+        return z
+
+    @torch.no_grad()
+    def sync(self, splats: Splats):
+        """Applies every pending SH step (brush_lazy_sh_flush): afterwards splats.sh_coeffs and the moments are what the
+        eager optimizer holds.  No-op when nothing is pending."""
+        if self._lazy is None or not self._lazy_pending:
+            return
+        sh = splats.sh_coeffs.detach()
+        n, ncoef = sh.shape[0], sh.shape[1]
+        z = self._lazy
+        z.now = self.opt_time
+        with torch.cuda.device(sh.device):
+            _lib.check(_lib.lib().brush_lazy_sh_flush(C.byref(z), sh.data_ptr(), n, R.sh_degree_from_coeffs(ncoef),
+                                                      torch.cuda.current_stream(sh.device).cuda_stream),
+                       "brush_lazy_sh_flush")
+        self._lazy_pending = False
+
     def _reset(self, n: int, ncoef: int, dev):
         """reset_stats + `self.optim = self.opt_config.init()` (train.rs:201-204,559-563)."""
+        self._lazy, self._lazy_bufs, self._lazy_pending = None, None, False
         self.grad_2d_accum = torch.zeros(n, device=dev)
         self.xy_grad_counts = torch.zeros(n, device=dev)
         self.moment1 = torch.zeros(n * (11 + 3 * ncoef), device=dev)
@@ -226,13 +283,20 @@ class SplatTrainer:
             with torch.cuda.device(means.device):
                 _lib.check(l.brush_normalize_quats(quats.data_ptr(), norm_rot.data_ptr(), n, stream), "brush_normalize_quats")
         self.invalidate_cached_rotation()
-        pred, aux, u = R._forward_impl(camera, (w, h), means, log_scales, norm_rot, sh, raw_opac, False, None)
+        fused = exchange is None and grad_sync is None and self.fused_backward
+        lazy = self._lazy_state(splats, n, ncoef) if fused else None
+        if lazy is None:
+            self.sync(splats)  # this step reads / steps every SH block: nothing may stay pending
+            self._lazy = None
+        pred, aux, u = R._forward_impl(camera, (w, h), means, log_scales, norm_rot, sh, raw_opac, False, None,
+                                       lazy_sh=lazy)
         if exchange is not None:
             exchange.begin(aux)  # the per-view counts start travelling while the loss and the backward run
         loss, v_pred = l1_ssim_loss(pred, gt_image, c.ssim_weight, c.ssim_window_size, 1.0 / batch_views)
         do_refine = self.iter < c.max_refine_step and self.iter >= c.warmup_steps and self.iter % c.refine_every == 1
         pre_step = None
         if do_refine:  # refinement clones / splits the parameters *before* the optimizer step (train.rs:361-372)
+            self.sync(splats)  # (the forward above has read the pending state; the clones need the eager values)
             pre_step = {"means": means.clone(), "rotation": quats.clone(), "sh": sh.clone(), "opac": raw_opac.clone(),
                         "scales": log_scales.clone()}
         cfg = _lib.BrushAdamConfig(self._lr_mean(scene_extent), c.lr_scale, c.lr_rotation, c.lr_opac,
@@ -240,6 +304,8 @@ class SplatTrainer:
                                    # v_pred carries 1/batch_views: keep the densification statistic at the magnitude the
                                    # reference's threshold was tuned for (batch 1, train.rs:284-316)
                                    float(batch_views))
+        if lazy is not None:
+            cfg.lazy_sh = C.pointer(lazy)
         want_stats = self.iter > c.warmup_steps  # housekeeping, train.rs:284-316
         with torch.cuda.device(means.device):
             if exchange is not None:
@@ -297,6 +363,10 @@ class SplatTrainer:
                                              stream),
                            "brush_adam_step")
         self.opt_time += 1
+        if lazy is not None:
+            self._lazy_pending = True
+        if do_refine:
+            self.sync(splats)  # refinement reads the post-step coefficients of every splat
         self.last_refine = self.refine_splats(splats, pre_step) if do_refine else None
         self.iter += 1
         return loss, pred, aux

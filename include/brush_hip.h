@@ -64,6 +64,31 @@ typedef struct BrushUniforms {
 #define BRUSH_TILE_WIDTH 16u
 #define BRUSH_PROJECTED_FLOATS 9u /* ProjectedSplat, helpers.wgsl:33-43 */
 
+/* Deferred Adam for the spherical-harmonics block (build extension of the training harness; optional everywhere it
+ * appears).  81 % of the optimizer's bytes at SH degree 3 are the coefficients and their two moments (48 of 59 floats
+ * per splat), yet the forward reads a splat's coefficients only when the splat passes the cull, and a splat that is
+ * not visible has a zero gradient.  With this state attached, the optimizer steps of a splat's SH block that carry a
+ * zero gradient are not applied when they happen; they stay pending and are replayed - the same float operations in the
+ * same order as burn's Adam::step would have run them, step by step, so the values are bit-identical to the eager
+ * optimizer - when the block is next needed: by the forward in registers (a pure read: the forward still modifies none
+ * of its inputs), by the fused backward before it applies the step that does carry a gradient, or by
+ * brush_lazy_sh_flush.  sh_time[g] is the optimizer time the stored SH block of splat g is current for.
+ * `table` row i holds (1 / (1 - beta1^t), 1 / (1 - beta2^t), lr_coeffs_dc, sh_rest_lerp) of optimizer time
+ * t = base + 1 + i, as brush_lazy_sh_fill_table computes them - the code that serves BrushAdamConfig::time in the fused
+ * eager step, so a replayed step uses the very floats the eager step was given; every pending time must lie inside the
+ * table: flush before `now` leaves it.  (Fused forms: the update is x - lr (m rbc1) rcp(sqrt(v rbc2) + eps) with
+ * v_sqrt_f32 / v_rcp_f32, 1 ulp each; WGSL specifies its division to 2.5 ulp.) */
+typedef struct BrushLazySh {
+    const float *table;   /* device, [capacity][4] */
+    uint32_t base;        /* optimizer time of row 0, minus 1 */
+    uint32_t capacity;
+    uint32_t now;         /* optimizer steps taken so far (the eager optimizer's `time` after its last step) */
+    uint32_t *sh_time;    /* device, [N]; <= now */
+    float *sh_moment1;    /* device, [N][C][3]: the SH segment of moment1 (moment1 + 11 N) */
+    float *sh_moment2;
+    float beta1, beta2, epsilon;
+} BrushLazySh;
+
 /* Device-pointer mirror of RenderAux (crates/brush-render/src/lib.rs:20-33).  All buffers are
  * caller-allocated with the shapes below and must stay alive and unmodified between
  * brush_render_forward and brush_render_backward (render.rs:436-446). */
@@ -100,6 +125,10 @@ typedef struct BrushAux {
                                           reference zero-fills inside the backward (render.rs:505-507); at 100 k
                                           visible splats that launch is 6 us of a 345 us step for 6.6 MB of stores the
                                           VALU-bound compositing kernel carries for free. */
+    const BrushLazySh *lazy_sh;        /* NULL, or the deferred-Adam state of the SH coefficients (host pointer, read
+                                          during the call only): the forward then evaluates a visible splat's colour
+                                          from its coefficients with the pending zero-gradient steps replayed in
+                                          registers.  `sh_coeffs` itself is not written. */
 } BrushAux;
 
 /* BrushAux::flags */
@@ -260,6 +289,11 @@ typedef struct BrushAdamConfig {
      * statistic the densification threshold is compared with (train.rs:284-316, tuned for B = 1) would shrink B-fold:
      * pass B here to keep the reference's magnitude.  0 is read as 1. */
     float xy_stat_scale;
+    /* Fused forms only (brush_render_backward_adam): NULL, or the deferred-Adam state of the SH block.  The SH
+     * coefficients and moments of splats the view does not see are then left alone (their step stays pending); a
+     * visible splat's block first has its pending steps replayed, then takes this step, and its sh_time becomes
+     * `time`.  Requires lazy_sh->now + 1 == time and 3 C floats per row a multiple of 4 (SH degree 1 or 3). */
+    const BrushLazySh *lazy_sh;
 } BrushAdamConfig;
 /* One Adam step on all five parameter groups in one launch.  v_*: the gradient arrays of
  * brush_render_backward; moment1 / moment2: N*(11+3C) floats each, owned by the caller, laid out
@@ -299,6 +333,14 @@ int brush_reduce_view_records_adam(const float *records, uint32_t num_views, uin
                                    float *raw_opacity, float *sh, uint32_t n, uint32_t sh_degree, float *moment1,
                                    float *moment2, float *next_quats_fed, float *grad_2d_accum, float *xy_grad_counts,
                                    void *view_index, size_t view_index_bytes, brush_stream_t stream);
+/* Applies every pending step of every splat's SH block (sh [N][C][3] and the two SH moment segments of `lazy`) and sets
+ * sh_time[g] = lazy->now for all g: afterwards sh / moments are what the eager optimizer would hold.  Call it before
+ * anything reads the coefficients without going through the op (export, refinement, a switch back to the eager step). */
+int brush_lazy_sh_flush(const BrushLazySh *lazy, float *sh, uint32_t n, uint32_t sh_degree, brush_stream_t stream);
+/* Host helper: rows [capacity][4] of BrushLazySh::table for optimizer times base+1 .. base+capacity, computed by the
+ * code that turns BrushAdamConfig::time into the bias corrections of an eager step (so both use the same floats). */
+int brush_lazy_sh_fill_table(float beta1, float beta2, float lr_coeffs_dc, float sh_rest_lerp, uint32_t base,
+                             uint32_t capacity, float *host_rows);
 /* normalized[i] = rotation[i] / |rotation[i]| (gaussian_splats.rs:174-175); [N,4], 16-byte aligned. */
 int brush_normalize_quats(const float *rotation, float *normalized, uint32_t n, brush_stream_t stream);
 /* train.rs:284-316: grad_2d_accum[g] += |v_xy[g] * (w/2, h/2)|; xy_grad_counts[g] += 1 for every

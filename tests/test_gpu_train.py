@@ -197,6 +197,7 @@ def test_hip_trainer_tracks_torch_trainer(dev):
         la, _, _ = ta.step(a, cam, gt)
         lb, _, _ = tb.step(b, cam, gt)
         assert abs(float(la) - float(lb)) <= (1e-5 if i == 0 else 2e-4), (i, float(la), float(lb))
+    ta.sync(a)
     # Adam's first steps move every touched parameter by ~lr regardless of gradient size, so a
     # sign flip of a ~0 gradient is a 2*lr difference: compare in units of the learning rate.
     for name, lr in (("means", cfg.lr_mean), ("log_scales", cfg.lr_scale), ("rotation", cfg.lr_rotation),
@@ -325,6 +326,7 @@ def test_fused_backward_adam_equals_separate_calls(dev, n, deg):
         la, _, _ = ta.step(a, cam, gt)
         lb, _, _ = tb.step(b, cam, gt)
         assert abs(float(la) - float(lb)) <= 2e-5, (i, float(la), float(lb))
+    ta.sync(a), tb.sync(b)
     for name, lr in (("means", cfg.lr_mean), ("log_scales", cfg.lr_scale), ("rotation", cfg.lr_rotation),
                      ("raw_opacity", cfg.lr_opac), ("sh_coeffs", cfg.lr_coeffs_dc)):
         d = (getattr(a, name).detach() - getattr(b, name).detach()).abs()
@@ -333,3 +335,118 @@ def test_fused_backward_adam_equals_separate_calls(dev, n, deg):
     assert float((ta.moment2 - tb.moment2).abs().max()) <= 1e-4 * float(tb.moment2.abs().max())
     assert torch.equal(ta.xy_grad_counts, tb.xy_grad_counts)
     assert float((ta.grad_2d_accum - tb.grad_2d_accum).abs().max()) <= 1e-3 * float(tb.grad_2d_accum.abs().max())
+
+
+def _orbit_cameras(w, h, count):
+    """Cameras on a circle around the cloud, each looking at its centre: every view sees a different subset."""
+    import math
+
+    import brush_amd
+
+    cams = []
+    for i in range(count):
+        a = 2.0 * math.pi * i / count
+        pos = [4.0 * math.sin(a), 0.0, -4.0 * math.cos(a)]
+        # rotation about +y by `a` (xyzw), so that the camera's +z axis points at the origin
+        rot = [0.0, -math.sin(a / 2.0), 0.0, math.cos(a / 2.0)]
+        cams.append(brush_amd.Camera(pos, rot, 0.4, 0.3, (0.5, 0.5)))
+    return cams
+
+
+@pytest.mark.parametrize("n,deg,table_rows", [(4000, 3, 2048), (4096, 1, 2048), (4000, 3, 5)])
+def test_deferred_sh_adam_equals_eager_bitwise(dev, n, deg, table_rows):
+    """Deferred Adam of the SH block (BrushLazySh): the optimizer steps of splats a view does not see stay pending and
+    are replayed when the block is next needed.  In deterministic mode (bitwise reproducible gradients) a run over views
+    with changing visibility must give the SAME BITS as the eager optimizer: the loss of every step (the forward renders
+    from the replayed coefficients), and after sync() every parameter and both moments.  table_rows = 5 forces the
+    per-step constant table to be rebuilt (flush + new base) several times inside the run."""
+    import torch
+
+    import brush_amd
+    from brush_amd import render as R
+
+    cloud = H.synthetic_cloud(n, deg, seed=21, mean_mult=0.0003)
+    cloud["log_scales"] = cloud["log_scales"] - 3.5
+    w, h = 160, 96
+    cams = _orbit_cameras(w, h, 5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mk = lambda: brush_amd.Splats(t(cloud["means"]), t(cloud["sh"]), t(cloud["quats"]), t(cloud["raw_opac"]),
+                                  t(cloud["log_scales"]))
+    torch.manual_seed(8)
+    gts = [torch.rand((h, w, 3), device=dev) for _ in cams]
+    a, b = mk(), mk()
+    ta = brush_amd.SplatTrainer(a, brush_amd.TrainConfig(warmup_steps=0, max_refine_step=0, deferred_sh_adam=True))
+    tb = brush_amd.SplatTrainer(b, brush_amd.TrainConfig(warmup_steps=0, max_refine_step=0, deferred_sh_adam=False))
+    ta.LAZY_TABLE_ROWS = table_rows
+    order = [0, 1, 2, 3, 4, 2, 0, 3, 3, 1, 4, 0, 2]
+    saved, R.DETERMINISTIC = R.DETERMINISTIC, True
+    try:
+        seen = torch.zeros(n, dtype=torch.bool, device=dev)
+        lagged = 0
+        for i, v in enumerate(order):
+            la, _, aux = ta.step(a, cams[v], gts[v])
+            lb, _, _ = tb.step(b, cams[v], gts[v])
+            assert float(la) == float(lb), (i, float(la), float(lb))
+            V = aux.read_num_visible()
+            assert 0 < V < n
+            seen[aux.global_from_compact_gid[:V].long()] = True
+            if ta._lazy is not None:
+                lagged = max(lagged, int((ta._lazy_bufs[0] < ta.opt_time).sum()))
+        assert ta._lazy is not None and lagged > 0, "nothing was deferred: the test would prove nothing"
+        if table_rows > len(order):
+            # before the flush the stored coefficients of some splats ARE behind the eager ones
+            assert not torch.equal(a.sh_coeffs.detach(), b.sh_coeffs.detach())
+        ta.sync(a)
+        assert bool((ta._lazy_bufs[0] == ta.opt_time).all())
+        for name in ("means", "log_scales", "rotation", "raw_opacity", "sh_coeffs"):
+            assert torch.equal(getattr(a, name).detach(), getattr(b, name).detach()), name
+        assert torch.equal(ta.moment1, tb.moment1) and torch.equal(ta.moment2, tb.moment2)
+        assert torch.equal(ta.grad_2d_accum, tb.grad_2d_accum) and torch.equal(ta.xy_grad_counts, tb.xy_grad_counts)
+        # a reader that bypasses the trainer: Splats.render syncs by itself and sees the eager image
+        ta.step(a, cams[1], gts[1]), tb.step(b, cams[1], gts[1])
+        ia, _ = a.render(cams[3], (w, h))
+        ib, _ = b.render(cams[3], (w, h))
+        assert torch.equal(ia, ib)
+    finally:
+        R.DETERMINISTIC = saved
+
+
+def test_deferred_sh_adam_through_refinement(dev):
+    """Refinement clones / splits / prunes whole parameter rows (train.rs:395-579): the trainer flushes what is pending
+    before it takes the pre-step copies and before refine_splats reads the post-step coefficients, so a deferred run
+    and an eager run refine to the same splats, bit for bit (deterministic mode)."""
+    import torch
+
+    import brush_amd
+    from brush_amd import render as R
+
+    n, deg, w, h = 2000, 3, 160, 96
+    cloud = H.synthetic_cloud(n, deg, seed=23, mean_mult=0.0003)
+    cloud["log_scales"] = cloud["log_scales"] - 3.5
+    cams = _orbit_cameras(w, h, 3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mk = lambda: brush_amd.Splats(t(cloud["means"]), t(cloud["sh"]), t(cloud["quats"]), t(cloud["raw_opac"]),
+                                  t(cloud["log_scales"]))
+    torch.manual_seed(9)
+    gts = [torch.rand((h, w, 3), device=dev) for _ in cams]
+    a, b = mk(), mk()
+    kw = dict(warmup_steps=2, refine_every=4, densify_grad_thresh=1e-7, densify_size_thresh=0.05, cull_scale_thresh=50.0)
+    ta = brush_amd.SplatTrainer(a, brush_amd.TrainConfig(deferred_sh_adam=True, **kw))
+    tb = brush_amd.SplatTrainer(b, brush_amd.TrainConfig(deferred_sh_adam=False, **kw))
+    saved, R.DETERMINISTIC = R.DETERMINISTIC, True
+    try:
+        refined = 0
+        for i in range(11):
+            v = i % len(cams)
+            la, _, _ = ta.step(a, cams[v], gts[v])
+            lb, _, _ = tb.step(b, cams[v], gts[v])
+            assert float(la) == float(lb), i
+            assert a.num_splats() == b.num_splats(), i
+            refined += ta.last_refine is not None
+        assert refined >= 2 and a.num_splats() != n
+        ta.sync(a)
+        for name in ("means", "log_scales", "rotation", "raw_opacity", "sh_coeffs"):
+            assert torch.equal(getattr(a, name).detach(), getattr(b, name).detach()), name
+        assert torch.equal(ta.moment1, tb.moment1) and torch.equal(ta.moment2, tb.moment2)
+    finally:
+        R.DETERMINISTIC = saved
