@@ -461,14 +461,52 @@ def main():
         def train_step():
             trainer.step(splats, cam, gt, 1.0, world, None, txchg)
 
-        tsec = timed(train_step, args.train_steps, 3)
+        def timed_train(tr, sp, step_fn, steps):
+            """K iterations AND the flush of whatever optimizer steps they deferred (SplatTrainer.sync: the SH blocks
+            of splats the views never saw), inside the timed region: no optimizer work is left out of the clock."""
+            for _ in range(3):
+                step_fn()
+            tr.sync(sp)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_fn()
+            tr.sync(sp)
+            barrier()
+            return max_over_ranks(time.perf_counter() - t0)
+
+        tsec = timed_train(trainer, splats, train_step, args.train_steps)
         train = {"iters_per_s": round(args.train_steps / tsec, 2), "ms_per_iter": round(tsec * 1e3 / args.train_steps, 4),
                  "views_per_iter": n_gpus, "views_per_s": round(n_gpus * args.train_steps / tsec, 2), "steps": args.train_steps,
                  "what": "render + L1*0.8-SSIM*0.2 loss + backward + 5 Adam groups (train.rs:211-359), no refinement, "
                          "fused HIP loss kernels around the op; " + (
-                             "Adam inside the backward's last kernel (brush_render_backward_adam)" if world == 1 else
+                             "Adam inside the backward (brush_render_backward_adam) with the SH block's zero-gradient "
+                             "steps deferred and replayed bit-exactly (BrushLazySh); the final flush of the K iterations "
+                             "is inside the timed region" if world == 1 else
                              "per-view gradient records all-gathered (RCCL), summed per splat and fed straight into Adam "
                              "(brush_reduce_view_records_adam), densification statistics inside the records")}
+        if world == 1:
+            # the same K iterations with every Adam step applied when it happens (the reference's schedule), and both
+            # optimizers on a cycle of 8 different views (view_camera), where deferred blocks do get caught up by the
+            # forward and the backward of later views
+            def run(deferred, cams):
+                sp = brush_amd.Splats(p["means"], p["sh"], p["quats"], p["raw_opac"], p["log_scales"])
+                tr = brush_amd.SplatTrainer(sp, brush_amd.TrainConfig(warmup_steps=0, max_refine_step=0,
+                                                                      deferred_sh_adam=deferred))
+                i = [0]
+
+                def step_fn():
+                    tr.step(sp, cams[i[0] % len(cams)], gt, 1.0, 1, None, None)
+                    i[0] += 1
+
+                sec = timed_train(tr, sp, step_fn, args.train_steps)
+                del sp, tr
+                return round(sec * 1e3 / args.train_steps, 4)
+
+            train["eager_adam_ms_per_iter"] = run(False, [cam])
+            ring = [view_camera(v, w, h) for v in range(8)]
+            train["changing_views"] = {"views": 8, "ms_per_iter": run(True, ring), "eager_adam_ms_per_iter": run(False, ring),
+                                       "what": "the same iteration over a cycle of the 8 views of the multi-GPU bench"}
         if world > 1:
             # replicated parameters must stay replicated: compare a checksum of the updated parameters across ranks
             chk = torch.stack([splats.means.detach().double().sum(), splats.sh_coeffs.detach().double().sum(),

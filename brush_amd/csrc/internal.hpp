@@ -91,10 +91,6 @@ struct DetSumsArgs {
     const float *partials = nullptr;
     uint32_t cap = 0;
 };
-struct VisibleList {
-    const uint32_t *num_visible;          // [1]
-    const uint32_t *global_from_compact;  // [N], the first *num_visible valid
-};
 hipError_t launch_sum_isect_rows(const float *rows, const uint32_t *num_intersections, const uint32_t *cum_tiles_hit,
                                  uint32_t cap, float *v_compact, float *partials, hipStream_t s);
 hipError_t launch_project_backward(const ViewParams &vp, const float *means, const float *log_scales,
@@ -105,7 +101,6 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
                                    const AdamFuse *adam, const DetSumsArgs &det,
                                    bool prezeroed /* dense form only: the arrays are already zero (ZeroFill), the
                                    visible splats' rows alone are written */,
-                                   const VisibleList &lazy_view /* adam->lazy on: the visible splats in compact order */,
                                    hipStream_t s);
 // View-sharded data parallelism (project_bwd.hip): per-view 64-byte gradient records, their index by global id and
 // the deterministic per-splat sum over views (dense arrays, or straight into the Adam update when adam != nullptr).

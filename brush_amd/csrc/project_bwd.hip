@@ -682,87 +682,95 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
 //   k_adam_small_groups           one lane per splat, a plain stream over the 11 floats of means / log_scales / rotation /
 //       raw_opacity and their moments; a visible splat's gradient is its record.
 // Same expressions as store_gradients_or_step<ADAM>: the same bits as the all-in-one kernel.
-constexpr uint32_t kLazyThreads = kWave;  // one wave per workgroup: ~1600 waves of work at 1 M splats spread over every SIMD
 template <int DEG>
-__global__ __launch_bounds__(kLazyThreads) void k_project_backward_lazy(
+__global__ __launch_bounds__(kThreads) void k_project_backward_lazy(
     ViewParams vp, const float *means, const float *log_scales, const float *__restrict__ quats, const float *raw_opac,
-    const uint32_t *__restrict__ num_visible, const uint32_t *__restrict__ global_from_compact, float *v_compact,
-    float *__restrict__ v_xy, AdamFuse af, DetSums det) {
+    const uint32_t *__restrict__ compact_from_global, float *v_compact, float *__restrict__ v_xy, AdamFuse af,
+    DetSums det) {
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1), kRow = ncoef * 3, kChunks = kRow / 4;
     static_assert(kRow % 4 == 0, "rows of whole 16-byte chunks");
-    // per wave: what the 64 splats' SH rows need - global id, the time the stored block is current for, v_rgb, Y
-    constexpr uint32_t kFac = 5 + ncoef;
-    __shared__ float fac_all[kLazyThreads / kWave][kWave][kFac | 1u];
-    const uint32_t wv = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-    float(*fac)[kFac | 1u] = fac_all[wv];
-    const uint32_t n = vp.total_splats, V = min(*num_visible, n);
+    // A workgroup walks 256 CONSECUTIVE global ids (a launch over the visible splats in depth order gathers from nine
+    // arrays at random pages per lane and took 54 us for the same work: address translation, not bandwidth).  Its
+    // visible splats are compacted to the first lanes (as in k_project_backward), which run the VJP and leave what the
+    // SH rows need in LDS - global id, the time the stored block is current for, v_rgb, Y; then all 256 lanes share the
+    // rows' chunks, kChunks consecutive lanes per row.
+    constexpr uint32_t kFac = (5 + ncoef) | 1u;
+    __shared__ float fac[kThreads][kFac];
+    __shared__ uint32_t vis_cnt[kThreads / kWave];
+    __shared__ uint16_t vis_list[kThreads];
+    const uint32_t wv = threadIdx.x / kWave;
+    const uint32_t n = vp.total_splats;
     const size_t nn = n;
-    const uint32_t waves = gridDim.x * (kLazyThreads / kWave);
-    for (uint32_t c0 = (blockIdx.x * (kLazyThreads / kWave) + wv) * kWave; c0 < V; c0 += waves * kWave) {  // wave-uniform
-        const uint32_t c = c0 + lane;
-        uint32_t g = kInvalid;
-        if (c < V) {
-            g = global_from_compact[c];
-            float4 r0, r1, r2;
-            load_compact_sums(v_compact, det, c, r0, r1, r2);
-            float o_mean[3], o_scale[3], o_quat[4], o_xy[2], o_opac, vcol[3], Y[ncoef];
-            visible_splat_vjp<DEG>(vp, means, log_scales, quats, raw_opac, g, r0, r1, r2, o_mean, o_scale, o_quat, o_opac,
-                                   o_xy, vcol, Y);
-            const float vx = o_xy[0] * af.half_w, vy = o_xy[1] * af.half_h;  // train.rs:300-302
-            float4 *out = reinterpret_cast<float4 *>(v_compact) + (size_t)c * kCompactVec;
-            out[0] = make_float4(__uint_as_float(g), o_mean[0], o_mean[1], o_mean[2]);
-            out[1] = make_float4(o_scale[0], o_scale[1], o_scale[2], o_quat[0]);
-            out[2] = make_float4(o_quat[1], o_quat[2], o_quat[3], o_opac);
-            out[3] = make_float4(vcol[0], vcol[1], vcol[2], sqrtf(vx * vx + vy * vy));
-            reinterpret_cast<float2 *>(v_xy)[g] = make_float2(o_xy[0], o_xy[1]);
-            fac[lane][1] = __uint_as_float(af.lazy.sh_time[g]);
-            fac[lane][2] = vcol[0], fac[lane][3] = vcol[1], fac[lane][4] = vcol[2];
-#pragma unroll
-            for (uint32_t k = 0; k < ncoef; k++) fac[lane][5 + k] = Y[k];
-        }
-        fac[lane][0] = __uint_as_float(g);
-        __builtin_amdgcn_wave_barrier();
-        // The 64 SH blocks of the wave, kChunks consecutive lanes per row (whole lines per request); the three streams of
-        // up to six chunks per lane are requested together (the registers of the VJP are free again by now; all twelve of
-        // a degree-3 row need 479).  Catch up, then this step (gradient row = Y[k] * v_rgb, gather_grads.wgsl:186-222).
-        constexpr uint32_t kBatch = kChunks <= 6 ? kChunks : 6;
-        static_assert(kChunks % kBatch == 0, "whole batches");
-        for (uint32_t it0 = 0; it0 < kChunks; it0 += kBatch) {
-            float4 x[kBatch], mo[kBatch], vo[kBatch];
-            uint32_t gr_[kBatch];
-#pragma unroll
-            for (uint32_t u = 0; u < kBatch; u++) {
-                const uint32_t q = (it0 + u) * kWave + lane, r = q / kChunks, j = q - r * kChunks;
-                gr_[u] = __float_as_uint(fac[r][0]);
-                if (gr_[u] != kInvalid) {
-                    const size_t e = (size_t)gr_[u] * kRow + 4 * j;
-                    x[u] = *reinterpret_cast<const float4 *>(af.sh + e);
-                    mo[u] = *reinterpret_cast<const float4 *>(af.m1 + 11 * nn + e);
-                    vo[u] = *reinterpret_cast<const float4 *>(af.m2 + 11 * nn + e);
-                }
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < kBatch; u++) {
-                if (gr_[u] == kInvalid) continue;
-                const uint32_t q = (it0 + u) * kWave + lane, r = q / kChunks, j = q - r * kChunks;
-                const size_t e = (size_t)gr_[u] * kRow + 4 * j;
-                lazy_replay4(af.lazy, __float_as_uint(fac[r][1]), 4 * j, mo[u], vo[u], x[u]);
-                const uint32_t k0 = 4 * j;
-                const float4 gr = make_float4(fac[r][5 + (k0 + 0) / 3] * fac[r][2 + (k0 + 0) % 3],
-                                              fac[r][5 + (k0 + 1) / 3] * fac[r][2 + (k0 + 1) % 3],
-                                              fac[r][5 + (k0 + 2) / 3] * fac[r][2 + (k0 + 2) % 3],
-                                              fac[r][5 + (k0 + 3) / 3] * fac[r][2 + (k0 + 3) % 3]);
-                float4 st = adam_elem4(af, 11 * nn + e, gr, x[u], mo[u], vo[u], af.lr[4]);
-                st.x = k0 + 0 >= 3 ? x[u].x * (1.0f - af.sh_lerp) + st.x * af.sh_lerp : st.x;
-                st.y = k0 + 1 >= 3 ? x[u].y * (1.0f - af.sh_lerp) + st.y * af.sh_lerp : st.y;
-                st.z = k0 + 2 >= 3 ? x[u].z * (1.0f - af.sh_lerp) + st.z * af.sh_lerp : st.z;
-                st.w = k0 + 3 >= 3 ? x[u].w * (1.0f - af.sh_lerp) + st.w * af.sh_lerp : st.w;
-                *reinterpret_cast<float4 *>(af.sh + e) = st;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // the rows are read; the next round of the wave may overwrite them
-        if (g != kInvalid) af.lazy.sh_time[g] = af.lazy.now + 1u;
+    const uint32_t g_own = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t c_own = g_own < n ? compact_from_global[g_own] : kInvalid;
+    {
+        const uint64_t bal = __ballot(c_own != kInvalid);
+        if (lane_id() == 0) vis_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        uint32_t pos = __popcll(bal & lanemask_lt());
+        for (uint32_t w2 = 0; w2 < wv; w2++) pos += vis_cnt[w2];
+        if (c_own != kInvalid) vis_list[pos] = (uint16_t)threadIdx.x;
+        __syncthreads();
     }
+    const uint32_t nvis = vis_cnt[0] + vis_cnt[1] + vis_cnt[2] + vis_cnt[3];
+    if (nvis == 0) return;  // uniform over the workgroup
+    uint32_t g = kInvalid;
+    if (threadIdx.x < nvis) {
+        g = blockIdx.x * kThreads + vis_list[threadIdx.x];
+        const uint32_t c = compact_from_global[g];
+        float4 r0, r1, r2;
+        load_compact_sums(v_compact, det, c, r0, r1, r2);
+        float o_mean[3], o_scale[3], o_quat[4], o_xy[2], o_opac, vcol[3], Y[ncoef];
+        visible_splat_vjp<DEG>(vp, means, log_scales, quats, raw_opac, g, r0, r1, r2, o_mean, o_scale, o_quat, o_opac, o_xy,
+                               vcol, Y);
+        const float vx = o_xy[0] * af.half_w, vy = o_xy[1] * af.half_h;  // train.rs:300-302
+        float4 *out = reinterpret_cast<float4 *>(v_compact) + (size_t)c * kCompactVec;
+        out[0] = make_float4(__uint_as_float(g), o_mean[0], o_mean[1], o_mean[2]);
+        out[1] = make_float4(o_scale[0], o_scale[1], o_scale[2], o_quat[0]);
+        out[2] = make_float4(o_quat[1], o_quat[2], o_quat[3], o_opac);
+        out[3] = make_float4(vcol[0], vcol[1], vcol[2], sqrtf(vx * vx + vy * vy));
+        reinterpret_cast<float2 *>(v_xy)[g] = make_float2(o_xy[0], o_xy[1]);
+        float *f = fac[threadIdx.x];
+        f[0] = __uint_as_float(g), f[1] = __uint_as_float(af.lazy.sh_time[g]);
+        f[2] = vcol[0], f[3] = vcol[1], f[4] = vcol[2];
+#pragma unroll
+        for (uint32_t k = 0; k < ncoef; k++) f[5 + k] = Y[k];
+    }
+    __syncthreads();
+    // the SH blocks: catch up, then this step (gradient row = Y[k] * v_rgb, gather_grads.wgsl:186-222); two chunks per
+    // lane are requested together (~25 visible splats x 12 chunks over 256 lanes at 1 M splats)
+    const uint32_t total = nvis * kChunks;
+    for (uint32_t q0 = threadIdx.x; q0 < total; q0 += 2 * kThreads) {
+        float4 x[2], mo[2], vo[2];
+        size_t e[2];
+        uint32_t r[2], k0[2];
+#pragma unroll
+        for (uint32_t u = 0; u < 2; u++) {
+            const uint32_t q = q0 + u * kThreads;
+            if (q < total) {
+                r[u] = q / kChunks, k0[u] = (q - r[u] * kChunks) * 4u;
+                e[u] = (size_t)__float_as_uint(fac[r[u]][0]) * kRow + k0[u];
+                x[u] = *reinterpret_cast<const float4 *>(af.sh + e[u]);
+                mo[u] = *reinterpret_cast<const float4 *>(af.m1 + 11 * nn + e[u]);
+                vo[u] = *reinterpret_cast<const float4 *>(af.m2 + 11 * nn + e[u]);
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 2; u++) {
+            if (q0 + u * kThreads >= total) continue;
+            const float *f = fac[r[u]];
+            lazy_replay4(af.lazy, __float_as_uint(f[1]), k0[u], mo[u], vo[u], x[u]);
+            const float4 gr = make_float4(f[5 + (k0[u] + 0) / 3] * f[2 + (k0[u] + 0) % 3], f[5 + (k0[u] + 1) / 3] * f[2 + (k0[u] + 1) % 3],
+                                          f[5 + (k0[u] + 2) / 3] * f[2 + (k0[u] + 2) % 3], f[5 + (k0[u] + 3) / 3] * f[2 + (k0[u] + 3) % 3]);
+            float4 st = adam_elem4(af, 11 * nn + e[u], gr, x[u], mo[u], vo[u], af.lr[4]);
+            st.x = k0[u] + 0 >= 3 ? x[u].x * (1.0f - af.sh_lerp) + st.x * af.sh_lerp : st.x;
+            st.y = k0[u] + 1 >= 3 ? x[u].y * (1.0f - af.sh_lerp) + st.y * af.sh_lerp : st.y;
+            st.z = k0[u] + 2 >= 3 ? x[u].z * (1.0f - af.sh_lerp) + st.z * af.sh_lerp : st.z;
+            st.w = k0[u] + 3 >= 3 ? x[u].w * (1.0f - af.sh_lerp) + st.w * af.sh_lerp : st.w;
+            *reinterpret_cast<float4 *>(af.sh + e[u]) = st;
+        }
+    }
+    if (g != kInvalid) af.lazy.sh_time[g] = af.lazy.now + 1u;
 }
 
 // One lane per 16-byte chunk of the small-group parameter space [means 3N | log_scales 3N | rotation 4N | raw_opacity N]
@@ -1079,8 +1087,7 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
                                    const float *quats, const float *raw_opac,
                                    const uint32_t *compact_from_global, const float *v_compact, float *v_means,
                                    float *v_xy, float *v_scales, float *v_quats, float *v_sh, float *v_opac,
-                                   const AdamFuse *adam, const DetSumsArgs &dargs, bool prezeroed,
-                                   const VisibleList &lazy_view, hipStream_t s) {
+                                   const AdamFuse *adam, const DetSumsArgs &dargs, bool prezeroed, hipStream_t s) {
     const uint32_t n = vp.total_splats;
     if (n == 0) return hipSuccess;
     const dim3 grid(ceil_div(n, kThreads)), block(kThreads);
@@ -1088,14 +1095,13 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
     if (adam) af = *adam;
     const DetSums det{dargs.cum_tiles_hit, dargs.num_intersections, dargs.partials, dargs.cap};
     if (adam && af.lazy.on()) {  // SH block under deferred Adam: visible-splat kernel + small-group stream
-        const dim3 gv(min(ceil_div(n, kLazyThreads), 16384u)), bv(kLazyThreads);
         float *vc = const_cast<float *>(v_compact);  // the records go over the accumulator rows, each lane its own
         if (vp.sh_degree == 1)
-            hipLaunchKernelGGL(k_project_backward_lazy<1>, gv, bv, 0, s, vp, means, log_scales, quats, raw_opac,
-                               lazy_view.num_visible, lazy_view.global_from_compact, vc, v_xy, af, det);
+            hipLaunchKernelGGL(k_project_backward_lazy<1>, grid, block, 0, s, vp, means, log_scales, quats, raw_opac,
+                               compact_from_global, vc, v_xy, af, det);
         else
-            hipLaunchKernelGGL(k_project_backward_lazy<3>, gv, bv, 0, s, vp, means, log_scales, quats, raw_opac,
-                               lazy_view.num_visible, lazy_view.global_from_compact, vc, v_xy, af, det);
+            hipLaunchKernelGGL(k_project_backward_lazy<3>, grid, block, 0, s, vp, means, log_scales, quats, raw_opac,
+                               compact_from_global, vc, v_xy, af, det);
         hipLaunchKernelGGL(k_adam_small_groups, dim3((uint32_t)(((size_t)n * 11 / 4 + kThreads - 1) / kThreads)), block, 0,
                            s, af, n, compact_from_global, vc, v_xy);
         return hipGetLastError();

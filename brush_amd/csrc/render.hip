@@ -383,7 +383,7 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
     // GatherGrads + ProjectBackwards fused, dense outputs written once (render.rs:534-594)
     BRUSH_HIP_CHECK(launch_project_backward(vp, means, log_scales, quats, raw_opacity, aux.compact_from_global_gid,
                                             ws.v_compact, v_means, v_xy, v_scales, v_quats, v_sh, v_opac, adam, det,
-                                            filled, VisibleList{aux.num_visible, aux.global_from_compact_gid}, s));
+                                            filled, s));
     mark_bwd(s, 3);
     return BRUSH_OK;
 }
