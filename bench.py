@@ -111,12 +111,16 @@ def algorithmic_bytes(n, V, I, P, T, C, fwd_only=False):
     return n * (92 + 12 * C) + V * (356 + 12 * C) + I * (132 + 16 * p) + P * 56 + T * 24
 
 
-# Algorithmic HBM bytes of ONE launch of each single-kernel stage.
+# Algorithmic HBM bytes of ONE launch of each single-kernel stage.  Since round 4 the dense
+# gradients' zeros (N (52 + 12 C) bytes, SURVEY §8d's "dense v_* written exactly once") are stored by the compositing
+# backward in passing and the VJP kernel writes the visible splats' rows only: the bytes moved with the stage that
+# writes them, the whole-path sum is unchanged.
 def stage_bytes(stage, n, V, I, P, T, C):
     return {
         "rasterize": I * 40 + P * 20 + T * 8,              # isect gid + record gather, img + final_index
-        "rasterize_bwd": I * (40 + 36) + P * 36 + T * 8,   # gather + 9 float atomics / (tile,splat); out,v_out,final
-        "project_bwd": n * 4 + V * (40 + 36 + 4) + n * (52 + 12 * C),
+        # gather + 9 float atomics / (tile,splat); out, v_out, final_index; the zeros of the six dense gradient arrays
+        "rasterize_bwd": I * (40 + 36) + P * 36 + T * 8 + (n - V) * (52 + 12 * C),
+        "project_bwd": n * 4 + V * (40 + 36 + 4) + V * (52 + 12 * C),
         "project_visible": V * (4 + 40 + 12 * C + 4 + 36 + 4 + 4) + (n - V) * 4,
     }[stage]
 

@@ -111,6 +111,9 @@ def test_renders_at_all(dev):
         assert not bool(p.grad.any())
 
 
+_ORACLE_CACHE = {}
+
+
 def _run_pair(dev, cloud, w, h, sh_degree, max_intersects=None, v_out=None, camera=None, deterministic=None):
     """Run the GPU op and the oracle on identical inputs (the oracle gets the uniform words the
     GPU op actually used).  Returns (gpu dict, oracle dict)."""
@@ -125,15 +128,35 @@ def _run_pair(dev, cloud, w, h, sh_degree, max_intersects=None, v_out=None, came
                                        params["quats"], params["sh"], params["raw_opac"], False, max_intersects,
                                        deterministic=deterministic)
     u = uniforms_to_numpy(aux)
-    o_out, o_aux = O.render_forward(u, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["sh"],
-                                    cloud["raw_opac"], max_intersects=aux.max_intersects)
-    if v_out is None:
+    default_v_out = v_out is None
+    if default_v_out:
         rng = np.random.default_rng(7)
         v_out = (rng.standard_normal((h, w, 4)).astype(np.float32)) / np.float32(h * w)
     out.backward(_t(v_out, dev))
-    # End-to-end oracle gradients (oracle forward state) ...
-    o_g = O.render_backward(u, o_aux, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["raw_opac"],
-                            o_out, v_out)
+    # The oracle's own forward and end-to-end backward depend on the inputs only: the deterministic-mode module runs
+    # every parity case a second time in the same process (and the c3 cloud at the reference cap twice), so they are
+    # kept per (inputs fingerprint, uniforms, capacity) for the largest few cases instead of being recomputed.
+    key = None
+    if default_v_out:
+        import hashlib
+        hh = hashlib.sha1()
+        for k in ("means", "log_scales", "quats", "sh", "raw_opac"):
+            a = np.ascontiguousarray(cloud[k])
+            hh.update(str(a.shape).encode()), hh.update(a[:4096].tobytes()), hh.update(a[-4096:].tobytes())
+        hh.update(repr(sorted((k, np.asarray(v).tobytes()) for k, v in u.items())).encode())
+        key = (hh.hexdigest(), int(aux.max_intersects), w, h)
+    if key is not None and key in _ORACLE_CACHE:
+        o_out, o_aux, o_g = _ORACLE_CACHE[key]
+    else:
+        o_out, o_aux = O.render_forward(u, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["sh"],
+                                        cloud["raw_opac"], max_intersects=aux.max_intersects)
+        # End-to-end oracle gradients (oracle forward state) ...
+        o_g = O.render_backward(u, o_aux, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["raw_opac"],
+                                o_out, v_out)
+        if key is not None and 200_000 <= cloud["means"].shape[0] <= 4_000_000:
+            while len(_ORACLE_CACHE) >= 3:
+                _ORACLE_CACHE.pop(next(iter(_ORACLE_CACHE)))
+            _ORACLE_CACHE[key] = (o_out, o_aux, o_g)
     # ... and the backward in isolation: the oracle's backward fed with the forward state the GPU
     # backward consumed (the GPU's out_img and final_index).  The reference recovers
     # T_final = 1 - out.a (rasterize_backwards.wgsl:163), so on nearly opaque pixels a 1-ulp
