@@ -300,8 +300,10 @@ __device__ __forceinline__ void sh_colour(const ViewParams &vp, const float mean
 // k_project_visible then needs ONE gather per splat.
 // LAZY (BrushAux::lazy_sh): the SH block is under deferred Adam (lazy_sh.hpp): a visible splat's colour is evaluated
 // from its stored coefficients with the pending zero-gradient steps replayed in registers; nothing is written back.
+// (four waves per SIMD: the launch is 4 waves per SIMD at 1 M splats, one round; the LAZY degree-3 form would otherwise
+// take 130 registers and a second round)
 template <int DEG, bool LAZY = false>
-__global__ __launch_bounds__(kThreads) void k_project_cull(ViewParams vp, BrushUniforms u,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void k_project_cull(ViewParams vp, BrushUniforms u,
                                                            const float *__restrict__ means,
                                                            const float *__restrict__ log_scales,
                                                            const float *__restrict__ quats,
