@@ -212,7 +212,9 @@ int brush_bwd_workspace_size_ex(uint32_t n, uint32_t w, uint32_t h, uint32_t sh_
 /* Gradients in the parent order of render.rs:420-427,598-624:
  * v_means[N,3] v_xy[N,2] (global order, pixel units) v_scales[N,3] (log-space)
  * v_quats[N,4] v_sh[N,C,3] v_opac[N] — dense, every element written, 0 for non-visible
- * splats.  out_img / v_out are float[h,w,4]. */
+ * splats.  out_img / v_out are float[h,w,4].  The six gradient arrays are written from the first kernel of the call on
+ * (their zeros ride on the compositing backward): they must not overlap any input of the call, the aux buffers or the
+ * workspace — as separately allocated Burn tensors never do. */
 int brush_render_backward(const BrushUniforms *h_uniforms, const BrushAux *h_aux,
                           const float *means, const float *log_scales, const float *quats,
                           const float *raw_opacity, uint32_t n, const float *out_img,

@@ -146,7 +146,7 @@ def _run_pair(dev, cloud, w, h, sh_degree, max_intersects=None, v_out=None, came
         hh.update(repr(sorted((k, np.asarray(v).tobytes()) for k, v in u.items())).encode())
         key = (hh.hexdigest(), int(aux.max_intersects), w, h)
     if key is not None and key in _ORACLE_CACHE:
-        o_out, o_aux, o_g = _ORACLE_CACHE[key]
+        o_out, o_aux, o_g = _ORACLE_CACHE[key] = _ORACLE_CACHE.pop(key)  # (most recently used last)
     else:
         o_out, o_aux = O.render_forward(u, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["sh"],
                                         cloud["raw_opac"], max_intersects=aux.max_intersects)
@@ -154,7 +154,7 @@ def _run_pair(dev, cloud, w, h, sh_degree, max_intersects=None, v_out=None, came
         o_g = O.render_backward(u, o_aux, cloud["means"], cloud["log_scales"], cloud["quats"], cloud["raw_opac"],
                                 o_out, v_out)
         if key is not None and 200_000 <= cloud["means"].shape[0] <= 4_000_000:
-            while len(_ORACLE_CACHE) >= 3:
+            while len(_ORACLE_CACHE) >= 8:  # < 1 GB of host memory in all
                 _ORACLE_CACHE.pop(next(iter(_ORACLE_CACHE)))
             _ORACLE_CACHE[key] = (o_out, o_aux, o_g)
     # ... and the backward in isolation: the oracle's backward fed with the forward state the GPU

@@ -23,8 +23,10 @@ t0 = time.perf_counter()
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 for _ in range(K):
     trainer.step(splats, cam, gt)
+t_host = time.perf_counter()  # every launch of the K iterations is enqueued; the GPU may still be working
 torch.cuda.synchronize()
 t1 = time.perf_counter()
+print("host enqueue ms/iter", (t_host - t0) / K * 1e3)
 trainer.sync(splats)  # the deferred SH steps of the K iterations (every splat this camera never sees)
 torch.cuda.synchronize()
 t2 = time.perf_counter()
