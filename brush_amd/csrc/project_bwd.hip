@@ -675,34 +675,42 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
 
 // ---- fused backward + Adam with the SH block under deferred Adam (BrushAdamConfig::lazy_sh) ---------------------------
 // With the SH block out of the stream the all-in-one kernel above is a chain of small dependent memory phases per wave
-// (measured: 155 us at 1 M splats for 0.4 GB).  Two launches instead:
-//   k_project_backward_lazy<DEG>  one lane per VISIBLE splat, compact order: the projection VJP, its 64-byte record
-//       (the layout of k_project_backward_records) written over the splat's own accumulator row, v_xy[g], and the splat's
-//       SH block: pending zero-gradient steps replayed, this step applied, sh_time advanced.
-//   k_adam_small_groups           one lane per splat, a plain stream over the 11 floats of means / log_scales / rotation /
-//       raw_opacity and their moments; a visible splat's gradient is its record.
-// Same expressions as store_gradients_or_step<ADAM>: the same bits as the all-in-one kernel.
+// (measured: 155 us at 1 M splats for 0.4 GB).  k_project_backward_lazy is built for what is left: a workgroup owns 256
+// CONSECUTIVE global ids (a launch over the visible splats in depth order gathers from nine arrays at random pages per
+// lane: no faster) and runs three phases:
+//   1. its visible splats, compacted to the first lanes (as in k_project_backward): the projection VJP; the results
+//      the other phases need stay in LDS (per visible splat: global id, the time its stored SH block is current for,
+//      v_rgb, Y; per owned splat: the 11 small-group gradients and the screen-space statistic);
+//   2. the visible splats' SH blocks, kChunks consecutive lanes per row: pending zero-gradient steps replayed, this step
+//      applied, sh_time advanced (118 MB of read-modify-write at 1 M splats);
+//   3. the workgroup's share of the small-group stream: the 704 16-byte chunks of means / log_scales / rotation /
+//      raw_opacity of its 256 splats with their moments (285 MB at 1 M splats), three per lane requested together; the
+//      rotation chunks (one splat each) also carry the per-splat duties: chain rule through the normalisation,
+//      next_quats_fed, the refinement statistics, v_xy.
+// Workgroups in different phases overlap (latency / arithmetic against bandwidth), which two launches — a visible-splat
+// kernel (53 us) and a plain small-group stream (60 us at 4.7 TB/s) — could not.  Same expressions as
+// store_gradients_or_step<ADAM>: the same bits as the all-in-one kernel.  Requires n % 4 == 0 and 16-byte aligned
+// arrays (AdamFuse::vec_ok).
 template <int DEG>
 __global__ __launch_bounds__(kThreads) void k_project_backward_lazy(
     ViewParams vp, const float *means, const float *log_scales, const float *__restrict__ quats, const float *raw_opac,
-    const uint32_t *__restrict__ compact_from_global, float *v_compact, float *__restrict__ v_xy, AdamFuse af,
-    DetSums det) {
+    const uint32_t *__restrict__ compact_from_global, const float *__restrict__ v_compact, float *__restrict__ v_xy,
+    AdamFuse af, DetSums det) {
     constexpr uint32_t ncoef = (DEG + 1) * (DEG + 1), kRow = ncoef * 3, kChunks = kRow / 4;
     static_assert(kRow % 4 == 0, "rows of whole 16-byte chunks");
-    // A workgroup walks 256 CONSECUTIVE global ids (a launch over the visible splats in depth order gathers from nine
-    // arrays at random pages per lane and took 54 us for the same work: address translation, not bandwidth).  Its
-    // visible splats are compacted to the first lanes (as in k_project_backward), which run the VJP and leave what the
-    // SH rows need in LDS - global id, the time the stored block is current for, v_rgb, Y; then all 256 lanes share the
-    // rows' chunks, kChunks consecutive lanes per row.
     constexpr uint32_t kFac = (5 + ncoef) | 1u;
+    constexpr uint32_t kSmall = 13;  // mean3 scale3 quat4 opac | statistic | visible flag
     __shared__ float fac[kThreads][kFac];
+    __shared__ float small_g[kThreads][kSmall];
     __shared__ uint32_t vis_cnt[kThreads / kWave];
     __shared__ uint16_t vis_list[kThreads];
     const uint32_t wv = threadIdx.x / kWave;
-    const uint32_t n = vp.total_splats;
+    const uint32_t n = vp.total_splats, b0 = blockIdx.x * kThreads;
     const size_t nn = n;
-    const uint32_t g_own = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t g_own = b0 + threadIdx.x;
     const uint32_t c_own = g_own < n ? compact_from_global[g_own] : kInvalid;
+#pragma unroll
+    for (uint32_t k = 0; k < kSmall; k++) small_g[threadIdx.x][k] = 0.0f;  // a splat the view does not see: zero gradient
     {
         const uint64_t bal = __ballot(c_own != kInvalid);
         if (lane_id() == 0) vis_cnt[wv] = __popcll(bal);
@@ -713,10 +721,11 @@ __global__ __launch_bounds__(kThreads) void k_project_backward_lazy(
         __syncthreads();
     }
     const uint32_t nvis = vis_cnt[0] + vis_cnt[1] + vis_cnt[2] + vis_cnt[3];
-    if (nvis == 0) return;  // uniform over the workgroup
+    // ---- 1. VJP of the visible splats
     uint32_t g = kInvalid;
     if (threadIdx.x < nvis) {
-        g = blockIdx.x * kThreads + vis_list[threadIdx.x];
+        const uint32_t li = vis_list[threadIdx.x];
+        g = b0 + li;
         const uint32_t c = compact_from_global[g];
         float4 r0, r1, r2;
         load_compact_sums(v_compact, det, c, r0, r1, r2);
@@ -724,12 +733,12 @@ __global__ __launch_bounds__(kThreads) void k_project_backward_lazy(
         visible_splat_vjp<DEG>(vp, means, log_scales, quats, raw_opac, g, r0, r1, r2, o_mean, o_scale, o_quat, o_opac, o_xy,
                                vcol, Y);
         const float vx = o_xy[0] * af.half_w, vy = o_xy[1] * af.half_h;  // train.rs:300-302
-        float4 *out = reinterpret_cast<float4 *>(v_compact) + (size_t)c * kCompactVec;
-        out[0] = make_float4(__uint_as_float(g), o_mean[0], o_mean[1], o_mean[2]);
-        out[1] = make_float4(o_scale[0], o_scale[1], o_scale[2], o_quat[0]);
-        out[2] = make_float4(o_quat[1], o_quat[2], o_quat[3], o_opac);
-        out[3] = make_float4(vcol[0], vcol[1], vcol[2], sqrtf(vx * vx + vy * vy));
         reinterpret_cast<float2 *>(v_xy)[g] = make_float2(o_xy[0], o_xy[1]);
+        float *sg = small_g[li];
+        sg[0] = o_mean[0], sg[1] = o_mean[1], sg[2] = o_mean[2];
+        sg[3] = o_scale[0], sg[4] = o_scale[1], sg[5] = o_scale[2];
+        sg[6] = o_quat[0], sg[7] = o_quat[1], sg[8] = o_quat[2], sg[9] = o_quat[3];
+        sg[10] = o_opac, sg[11] = sqrtf(vx * vx + vy * vy), sg[12] = 1.0f;
         float *f = fac[threadIdx.x];
         f[0] = __uint_as_float(g), f[1] = __uint_as_float(af.lazy.sh_time[g]);
         f[2] = vcol[0], f[3] = vcol[1], f[4] = vcol[2];
@@ -737,8 +746,8 @@ __global__ __launch_bounds__(kThreads) void k_project_backward_lazy(
         for (uint32_t k = 0; k < ncoef; k++) f[5 + k] = Y[k];
     }
     __syncthreads();
-    // the SH blocks: catch up, then this step (gradient row = Y[k] * v_rgb, gather_grads.wgsl:186-222); two chunks per
-    // lane are requested together (~25 visible splats x 12 chunks over 256 lanes at 1 M splats)
+    // ---- 2. the SH blocks: catch up, then this step (gradient row = Y[k] * v_rgb, gather_grads.wgsl:186-222); two
+    // chunks per lane are requested together (~25 visible splats x 12 chunks over 256 lanes at 1 M splats)
     const uint32_t total = nvis * kChunks;
     for (uint32_t q0 = threadIdx.x; q0 < total; q0 += 2 * kThreads) {
         float4 x[2], mo[2], vo[2];
@@ -771,67 +780,65 @@ __global__ __launch_bounds__(kThreads) void k_project_backward_lazy(
         }
     }
     if (g != kInvalid) af.lazy.sh_time[g] = af.lazy.now + 1u;
-}
-
-// One lane per 16-byte chunk of the small-group parameter space [means 3N | log_scales 3N | rotation 4N | raw_opacity N]
-// (the layout of the moment arrays): three streaming loads, three streaming stores, nothing else resident.  A chunk of
-// means / log_scales spans two splats, a chunk of raw_opacity four: each element looks its splat up (neighbouring lanes
-// share the words) and a visible splat's gradient is a field of its record.  The rotation chunks (one splat each) also
-// carry the per-splat duties: chain rule through the normalisation, next_quats_fed, the refinement statistics, and the
-// zero v_xy of a splat the view does not see.  Requires n % 4 == 0 and 16-byte aligned arrays (AdamFuse::vec_ok).
-__global__ __launch_bounds__(kThreads) void k_adam_small_groups(AdamFuse af, uint32_t n,
-                                                                const uint32_t *__restrict__ compact_from_global,
-                                                                const float *__restrict__ records,
-                                                                float *__restrict__ v_xy) {
-    const size_t nn = n;
-    const size_t e0 = ((size_t)blockIdx.x * kThreads + threadIdx.x) * 4;  // first float of the chunk in moment order
-    if (e0 >= 11 * nn) return;
-    float *p;
-    size_t rel;
-    float lr;
-    uint32_t rowf, field0;  // floats per splat in this segment; record word of its first component
-    if (e0 < 3 * nn) p = af.means, rel = e0, lr = af.lr[0], rowf = 3, field0 = 1;
-    else if (e0 < 6 * nn) p = af.log_scales, rel = e0 - 3 * nn, lr = af.lr[1], rowf = 3, field0 = 4;
-    else if (e0 < 10 * nn) p = af.rotation, rel = e0 - 6 * nn, lr = af.lr[2], rowf = 4, field0 = 7;
-    else p = af.raw_opac, rel = e0 - 10 * nn, lr = af.lr[3], rowf = 1, field0 = 11;
-    float4 x = nt_load4(p + rel);
-    const float4 mo = nt_load4(af.m1 + e0), vo = nt_load4(af.m2 + e0);
-    float gr[4];
-    uint32_t c_first = kInvalid;
+    // ---- 3. the small groups of the workgroup's splats, as 16-byte chunks in the order of the moment arrays
+    const uint32_t nb = min(kThreads, n - b0);                      // splats owned (a multiple of 4)
+    const uint32_t c3 = nb * 3u / 4u, cq = nb, co = nb / 4u;         // chunks of means (= log_scales), rotation, raw_opacity
+    const uint32_t chunks = 2u * c3 + cq + co;
+    constexpr uint32_t kPer = 3;                                     // 704 chunks over 256 lanes
+    float4 x[kPer], mo[kPer], vo[kPer];
+    float *p[kPer];
+    size_t rel[kPer], e0[kPer];
+    uint32_t rowf[kPer], field0[kPer];
+    float lr[kPer];
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
-        const uint32_t gi = (uint32_t)((rel + i) / rowf), comp = (uint32_t)((rel + i) - (size_t)gi * rowf);
-        const uint32_t c = compact_from_global[gi];
-        if (i == 0) c_first = c;
-        gr[i] = c != kInvalid ? records[(size_t)c * kRecFloats + field0 + comp] : 0.0f;
+    for (uint32_t u = 0; u < kPer; u++) {
+        const uint32_t q = threadIdx.x + u * kThreads;
+        if (q >= chunks) continue;
+        if (q < c3) p[u] = af.means, rel[u] = (size_t)b0 * 3 + q * 4u, e0[u] = rel[u], lr[u] = af.lr[0], rowf[u] = 3, field0[u] = 0;
+        else if (q < 2u * c3) p[u] = af.log_scales, rel[u] = (size_t)b0 * 3 + (q - c3) * 4u, e0[u] = 3 * nn + rel[u], lr[u] = af.lr[1], rowf[u] = 3, field0[u] = 3;
+        else if (q < 2u * c3 + cq) p[u] = af.rotation, rel[u] = (size_t)b0 * 4 + (q - 2u * c3) * 4u, e0[u] = 6 * nn + rel[u], lr[u] = af.lr[2], rowf[u] = 4, field0[u] = 6;
+        else p[u] = af.raw_opac, rel[u] = (size_t)b0 + (q - 2u * c3 - cq) * 4u, e0[u] = 10 * nn + rel[u], lr[u] = af.lr[3], rowf[u] = 1, field0[u] = 10;
+        x[u] = nt_load4(p[u] + rel[u]);
+        mo[u] = nt_load4(af.m1 + e0[u]);
+        vo[u] = nt_load4(af.m2 + e0[u]);
     }
-    float4 g4 = make_float4(gr[0], gr[1], gr[2], gr[3]);
-    if (rowf == 4) {  // one splat per chunk: the per-splat duties ride here
-        const uint32_t g = (uint32_t)(rel / 4);
-        const bool vis = c_first != kInvalid;
-        if (af.quat_vjp) {  // the op was fed rot/|rot| (gaussian_splats.rs:174-175); chain v_q to the raw parameter
-            const float s2 = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
-            const float inv_s = 1.0f / sqrtf(s2);
-            const float dot = (g4.x * x.x + g4.y * x.y + g4.z * x.z + g4.w * x.w) * (inv_s * inv_s * inv_s);
-            g4 = make_float4(g4.x * inv_s - x.x * dot, g4.y * inv_s - x.y * dot, g4.z * inv_s - x.z * dot,
-                             g4.w * inv_s - x.w * dot);
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; u++) {
+        const uint32_t q = threadIdx.x + u * kThreads;
+        if (q >= chunks) continue;
+        float gr[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t gi = (uint32_t)((rel[u] + i) / rowf[u]);
+            gr[i] = small_g[gi - b0][field0[u] + (uint32_t)((rel[u] + i) - (size_t)gi * rowf[u])];
         }
-        if (af.grad_2d_accum) {  // train.rs:284-316
-            const float stat_norm = vis ? records[(size_t)c_first * kRecFloats + 15] : 0.0f;
-            af.grad_2d_accum[g] += stat_norm * af.stat_scale;
-            if (vis) af.xy_grad_counts[g] += 1.0f;
+        float4 g4 = make_float4(gr[0], gr[1], gr[2], gr[3]);
+        if (rowf[u] == 4) {  // one splat per chunk: the per-splat duties ride here
+            const uint32_t gs = (uint32_t)(rel[u] / 4), l = gs - b0;
+            const bool vis = small_g[l][12] != 0.0f;
+            if (af.quat_vjp) {  // the op was fed rot/|rot| (gaussian_splats.rs:174-175); chain v_q to the raw parameter
+                const float4 r = x[u];
+                const float s2 = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+                const float inv_s = 1.0f / sqrtf(s2);
+                const float dot = (g4.x * r.x + g4.y * r.y + g4.z * r.z + g4.w * r.w) * (inv_s * inv_s * inv_s);
+                g4 = make_float4(g4.x * inv_s - r.x * dot, g4.y * inv_s - r.y * dot, g4.z * inv_s - r.z * dot,
+                                 g4.w * inv_s - r.w * dot);
+            }
+            if (af.grad_2d_accum) {  // train.rs:284-316
+                af.grad_2d_accum[gs] += small_g[l][11] * af.stat_scale;
+                if (vis) af.xy_grad_counts[gs] += 1.0f;
+            }
+            if (!vis) reinterpret_cast<float2 *>(v_xy)[gs] = make_float2(0.f, 0.f);  // (visible: phase 1)
+            const float4 st = adam_elem4(af, e0[u], g4, x[u], mo[u], vo[u], lr[u]);
+            nt_store4(p[u] + rel[u], st);
+            if (af.norm_rot_out) {  // what the next forward will be fed (gaussian_splats.rs:174-175)
+                const float sn = sqrtf(st.x * st.x + st.y * st.y + st.z * st.z + st.w * st.w);
+                reinterpret_cast<float4 *>(af.norm_rot_out)[gs] = make_float4(st.x / sn, st.y / sn, st.z / sn, st.w / sn);
+            }
+        } else {
+            nt_store4(p[u] + rel[u], adam_elem4(af, e0[u], g4, x[u], mo[u], vo[u], lr[u]));
         }
-        if (!vis) reinterpret_cast<float2 *>(v_xy)[g] = make_float2(0.f, 0.f);  // (visible: k_project_backward_lazy)
-        x = adam_elem4(af, e0, g4, x, mo, vo, lr);
-        nt_store4(p + rel, x);
-        if (af.norm_rot_out) {  // what the next forward will be fed (gaussian_splats.rs:174-175)
-            const float s = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
-            reinterpret_cast<float4 *>(af.norm_rot_out)[g] = make_float4(x.x / s, x.y / s, x.z / s, x.w / s);
-        }
-        return;
     }
-    x = adam_elem4(af, e0, g4, x, mo, vo, lr);
-    nt_store4(p + rel, x);
 }
 
 // ---- view-sharded data parallelism: per-view gradient records and their deterministic reduction ------------
@@ -1094,16 +1101,13 @@ hipError_t launch_project_backward(const ViewParams &vp, const float *means, con
     AdamFuse af{};
     if (adam) af = *adam;
     const DetSums det{dargs.cum_tiles_hit, dargs.num_intersections, dargs.partials, dargs.cap};
-    if (adam && af.lazy.on()) {  // SH block under deferred Adam: visible-splat kernel + small-group stream
-        float *vc = const_cast<float *>(v_compact);  // the records go over the accumulator rows, each lane its own
+    if (adam && af.lazy.on()) {  // SH block under deferred Adam
         if (vp.sh_degree == 1)
             hipLaunchKernelGGL(k_project_backward_lazy<1>, grid, block, 0, s, vp, means, log_scales, quats, raw_opac,
-                               compact_from_global, vc, v_xy, af, det);
+                               compact_from_global, v_compact, v_xy, af, det);
         else
             hipLaunchKernelGGL(k_project_backward_lazy<3>, grid, block, 0, s, vp, means, log_scales, quats, raw_opac,
-                               compact_from_global, vc, v_xy, af, det);
-        hipLaunchKernelGGL(k_adam_small_groups, dim3((uint32_t)(((size_t)n * 11 / 4 + kThreads - 1) / kThreads)), block, 0,
-                           s, af, n, compact_from_global, vc, v_xy);
+                               compact_from_global, v_compact, v_xy, af, det);
         return hipGetLastError();
     }
 #define BRUSH_LAUNCH_PB(D)                                                                                      \
