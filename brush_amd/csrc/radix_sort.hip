@@ -507,9 +507,19 @@ hipError_t sort_launch(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
     if (lds != hipSuccess) return lds;
     const bool fused = sort_is_fused(max_n);
     const uint32_t *src_k = keys_in, *src_v = vals_in;
+    // Internal callers that bound the key values (edge_keys: every key < edge_keys, the tile sort) get the significant
+    // bits split evenly over the passes instead of 8 + the rest: a 13-bit tile id is sorted as 7 + 6 bits, so the first
+    // pass scatters into 128 runs per tile instead of 256 (runs twice as long: fewer partial lines written).  Same
+    // result: the bits above the bound are zero in every key.
+    uint32_t even_width = 0;
+    if (edge_keys > 1u) {
+        uint32_t sig = 0;
+        while (sig < 32u && ((edge_keys - 1u) >> sig) != 0u) sig++;
+        if (sig <= total_bits) even_width = (sig + passes - 1u) / passes;
+    }
     for (uint32_t p = 0; p < passes; p++) {
-        const uint32_t shift = p * 8u;
-        const uint32_t width = min(8u, total_bits - shift);
+        const uint32_t shift = even_width ? p * even_width : p * 8u;
+        const uint32_t width = even_width ? even_width : min(8u, total_bits - shift);
         const uint32_t mask = (1u << width) - 1u;
         const bool to_out = ((passes - 1 - p) % 2u) == 0;
         uint32_t *dst_k = to_out ? keys_out : w.tmp_keys;  // keys_out may be nullptr: the last pass then writes no keys
