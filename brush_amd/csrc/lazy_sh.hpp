@@ -9,6 +9,8 @@
 // adam_elem4() / copy_out() of project_bwd.hip with g = 0, and every translation unit that includes this file is built
 // with -ffp-contract=off, so a replayed step rounds exactly as the eager one would have.
 #pragma once
+#include <math.h>
+
 #include "common.hpp"
 
 namespace brush {
@@ -38,6 +40,13 @@ inline bool make_lazy_sh(const BrushLazySh *l, uint32_t sh_degree, LazySh *out) 
     out->m1 = l->sh_moment1, out->m2 = l->sh_moment2;
     out->beta1 = l->beta1, out->beta2 = l->beta2, out->eps = l->epsilon;
     return true;
+}
+
+// burn 0.16 Adam::step divides by 1 - beta^time (f32); the kernels multiply by the reciprocals (adam_stepped()).  One
+// host function for every optimizer entry point and for the table of deferred steps.
+inline void adam_bias_corrections(float beta1, float beta2, uint32_t time, float *rbc1, float *rbc2) {
+    *rbc1 = 1.0f / (1.0f - powf(beta1, (float)time));
+    *rbc2 = 1.0f / (1.0f - powf(beta2, (float)time));
 }
 
 // The update of burn 0.16 Adam::step on one element (moments already advanced): x - lr (m / bc1) / (sqrt(v / bc2) + eps)

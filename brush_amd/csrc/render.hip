@@ -388,13 +388,6 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
     return BRUSH_OK;
 }
 
-// burn 0.16 Adam::step divides by 1 - beta^time (f32); the kernels multiply by the reciprocals (adam_stepped()).  One
-// function for the eager fused step and for the table of deferred steps.
-static void adam_bias_corrections(float beta1, float beta2, uint32_t time, float *rbc1, float *rbc2) {
-    *rbc1 = 1.0f / (1.0f - powf(beta1, (float)time));
-    *rbc2 = 1.0f / (1.0f - powf(beta2, (float)time));
-}
-
 extern "C" int brush_lazy_sh_fill_table(float beta1, float beta2, float lr_coeffs_dc, float sh_rest_lerp, uint32_t base,
                                         uint32_t capacity, float *host_rows) {
     if (!host_rows || base > 0xFFFFFFFFu - capacity) return BRUSH_ERR_INVALID_ARG;
