@@ -300,7 +300,10 @@ typedef struct BrushAdamConfig {
 /* One Adam step on all five parameter groups in one launch.  v_*: the gradient arrays of
  * brush_render_backward; moment1 / moment2: N*(11+3C) floats each, owned by the caller, laid out
  * [means 3N | log_scales 3N | quats 4N | raw_opac N | sh 3CN] and zero before the first step.
- * Parameters are updated in place. */
+ * Parameters are updated in place.  Every optimizer entry point of this header computes the update as
+ * x - lr (m rbc1) rcp(sqrt(v rbc2) + eps), rbc = 1 / (1 - beta^time) formed on the host, with v_sqrt_f32 / v_rcp_f32
+ * (1 ulp each; WGSL, which the reference's optimizer runs in, allows 2.5 ulp on a division) and no FMA contraction:
+ * from the same gradients the separate calls, the fused call and its deferred-SH form leave the same bits. */
 int brush_adam_step(const BrushAdamConfig *cfg, uint32_t n, uint32_t sh_degree, float *means, float *log_scales,
                     float *quats, float *raw_opac, float *sh, const float *v_means, const float *v_scales,
                     const float *v_quats, const float *v_opac, const float *v_sh, float *moment1,
