@@ -824,9 +824,9 @@ __global__ __launch_bounds__(kThreads) void k_project_backward_lazy(
                 g4 = make_float4(g4.x * inv_s - r.x * dot, g4.y * inv_s - r.y * dot, g4.z * inv_s - r.z * dot,
                                  g4.w * inv_s - r.w * dot);
             }
-            if (af.grad_2d_accum) {  // train.rs:284-316
+            if (af.grad_2d_accum && vis) {  // train.rs:284-316 (a splat the view does not see adds +0: left alone)
                 af.grad_2d_accum[gs] += small_g[l][11] * af.stat_scale;
-                if (vis) af.xy_grad_counts[gs] += 1.0f;
+                af.xy_grad_counts[gs] += 1.0f;
             }
             if (!vis) reinterpret_cast<float2 *>(v_xy)[gs] = make_float2(0.f, 0.f);  // (visible: phase 1)
             const float4 st = adam_elem4(af, e0[u], g4, x[u], mo[u], vo[u], lr[u]);
