@@ -75,7 +75,9 @@ __device__ __forceinline__ void lazy_step_elem(const LazySh &z, const float4 c, 
 
 // The pending steps t0+1 .. z.now of one 16-byte chunk; k0 = position of its first float in the splat's row.
 __device__ __forceinline__ void lazy_replay4(const LazySh &z, uint32_t t0, uint32_t k0, float4 &m, float4 &v, float4 &x) {
-    for (uint32_t t = t0; t < z.now; t++) {
+    // (a block older than the table — a caller that did not flush before rebasing — is replayed from the table's first
+    // row on: wrong values for that misuse, but never a read in front of the table)
+    for (uint32_t t = max(t0, z.base); t < z.now; t++) {
         const float4 c = z.table[t - z.base];  // row of optimizer time t + 1
         lazy_step_elem(z, c, k0 + 0u >= 3u, m.x, v.x, x.x);
         lazy_step_elem(z, c, k0 + 1u >= 3u, m.y, v.y, x.y);
