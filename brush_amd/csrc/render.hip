@@ -374,6 +374,10 @@ static int render_backward_impl(const BrushUniforms *h_uniforms, const BrushAux 
         float *const arrays[kFillSegs] = {v_sh, v_means, v_scales, v_quats, v_opac, v_xy};
         const size_t floats[kFillSegs] = {nn * C * 3, nn * 3, nn * 3, nn * 4, nn, nn * 2};
         (void)make_zero_fill(&fill, arrays, floats, kFillSegs);  // (unaligned / oversized arrays: zeros stay in the VJP kernel)
+        // a frame of a few tiles has a few waves: more than 1 MiB of zeros per tile would turn the compositing launch
+        // into a slow fill (1 M splats on a 64 x 64 frame); the all-in-one VJP kernel writes them at stream rate
+        const uint64_t tiles = (uint64_t)u.tile_bounds[0] * u.tile_bounds[1];
+        if (fill.first_block[kFillSegs] > 1024ull * (tiles ? tiles : 1ull)) fill = ZeroFill{};
     }
     mark_bwd(s, 0);
     DetSumsArgs det;

@@ -523,13 +523,14 @@ def test_tiny_and_empty_inputs(dev, n):
     _assert_grad_parity(gpu, orc)
 
 
-@pytest.mark.parametrize("n,deg,w,h", [(1003, 3, 200, 120), (1001, 2, 64, 48), (70001, 0, 640, 480), (5, 4, 32, 32)])
+@pytest.mark.parametrize("n,deg,w,h", [(1003, 3, 200, 120), (1001, 2, 64, 48), (70001, 0, 640, 480), (5, 4, 32, 32),
+                                       (200003, 3, 32, 32)])  # last: > 1 MiB of zeros per tile, the VJP kernel keeps them
 def test_dense_gradients_zeroed_in_passing(dev, n, deg, w, h):
     """The compositing backward zero-fills the dense gradient arrays beside its arithmetic (ZeroFill) and the VJP kernel
     writes the visible rows only: NaN-poisoned outputs must come back dense — exact zeros off the visible set, the same
     bits as the all-in-one VJP kernel on it — for splat counts that leave partial KiB blocks and 1-3 trailing floats in
-    every array, in both accumulation modes; arrays that are not 16-byte aligned take the old path (zeros written by the
-    VJP kernel) and must give the same bits."""
+    every array, in both accumulation modes; arrays that are not 16-byte aligned, and a cloud far too large for the
+    frame's few waves, take the old path (zeros written by the VJP kernel) and must give the same bits."""
     import torch
 
     import brush_amd
