@@ -488,7 +488,9 @@ def main():
                              "steps deferred and replayed bit-exactly (BrushLazySh); the final flush of the K iterations "
                              "is inside the timed region" if world == 1 else
                              "per-view gradient records all-gathered (RCCL), summed per splat and fed straight into Adam "
-                             "(brush_reduce_view_records_adam), densification statistics inside the records")}
+                             "(brush_reduce_view_records_adam), densification statistics inside the records; the SH "
+                             "blocks of splats no view of the batch saw stay pending (BrushLazySh), the final flush is "
+                             "inside the timed region")}
         if world == 1:
             # the same K iterations with every Adam step applied when it happens (the reference's schedule), and both
             # optimizers on a cycle of 8 different views (view_camera), where deferred blocks do get caught up by the

@@ -284,7 +284,9 @@ __device__ __forceinline__ float4 adam_elem4(const AdamFuse &a, size_t e, float4
 // `stage`: kStageFloats of LDS private to the wave.
 template <int DEG, bool ADAM, bool ROWS_READY>
 __device__ __forceinline__ void store_gradients_or_step(
-    const AdamFuse &af, uint32_t n, uint32_t g0, uint32_t lane, float *stage, const float o_mean[3],
+    const AdamFuse &af, uint32_t n, uint32_t g0, uint32_t lane, float *stage,
+    const uint32_t *row_t0 /* deferred SH (ROWS_READY form): per row of the wave, the time its block is current for */,
+    const float o_mean[3],
     const float o_scale[3], const float o_quat[4], float o_opac, const float o_xy[2], float stat_norm,
     float stat_count, const float *Y, const float vcol[3], float *__restrict__ v_means, float *__restrict__ v_xy,
     float *__restrict__ v_scales, float *__restrict__ v_quats, float *__restrict__ v_sh, float *__restrict__ v_opac) {
@@ -338,6 +340,33 @@ __device__ __forceinline__ void store_gradients_or_step(
     // gradient updates the parameter in place (SH coefficients >= 1 with the lerp of train.rs:336-351).
     auto copy_out = [&](float *dst, uint32_t rowf, uint32_t stride, size_t seg, float lr, bool is_sh) {
         const uint32_t total = rows * rowf;  // floats; dst is 16-B aligned when g0*rowf % 4 == 0
+        if constexpr (ADAM && ROWS_READY) {
+            if (is_sh && af.lazy.on()) {
+                // Deferred Adam of the SH block (lazy_sh.hpp) in the data-parallel reduction: the blocks of splats NO view
+                // saw are left alone, their step stays pending; a seen splat's block first replays what is pending, then
+                // takes this step.  Rows are whole 16-byte chunks (make_lazy_sh).
+                for (uint32_t j = lane * 4; j < total; j += kWave * 4) {
+                    const uint32_t r = j / rowf, k0 = j - r * rowf;
+                    const uint32_t t0 = row_t0[r];
+                    if (t0 == kInvalid) continue;
+                    float4 x = *reinterpret_cast<const float4 *>(dst + j);
+                    float4 mo = *reinterpret_cast<const float4 *>(af.m1 + seg + j);
+                    float4 vo = *reinterpret_cast<const float4 *>(af.m2 + seg + j);
+                    lazy_replay4(af.lazy, t0, k0, mo, vo, x);
+                    float4 v;
+                    float *e = reinterpret_cast<float *>(&v);
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) e[i] = stage[r * stride + k0 + i];
+                    float4 st = adam_elem4(af, seg + j, v, x, mo, vo, lr);
+                    st.x = k0 + 0 >= 3 ? x.x * (1.0f - af.sh_lerp) + st.x * af.sh_lerp : st.x;
+                    st.y = k0 + 1 >= 3 ? x.y * (1.0f - af.sh_lerp) + st.y * af.sh_lerp : st.y;
+                    st.z = k0 + 2 >= 3 ? x.z * (1.0f - af.sh_lerp) + st.z * af.sh_lerp : st.z;
+                    st.w = k0 + 3 >= 3 ? x.w * (1.0f - af.sh_lerp) + st.w * af.sh_lerp : st.w;
+                    *reinterpret_cast<float4 *>(dst + j) = st;
+                }
+                return;
+            }
+        }
         auto one = [&](uint32_t f) {
             const float gv = stage[(f / rowf) * stride + (f % rowf)];
             if (!ADAM) {
@@ -668,7 +697,7 @@ __global__ __launch_bounds__(kThreads) void k_project_backward(
         const float vx = o_xy[0] * af.half_w, vy = o_xy[1] * af.half_h;
         stat_norm = sqrtf(vx * vx + vy * vy);
     }
-    store_gradients_or_step<DEG, ADAM, false>(af, n, g0, lane, stage, o_mean, o_scale, o_quat, o_opac, o_xy, stat_norm,
+    store_gradients_or_step<DEG, ADAM, false>(af, n, g0, lane, stage, nullptr, o_mean, o_scale, o_quat, o_opac, o_xy, stat_norm,
                                               c_own != kInvalid ? 1.0f : 0.0f, Y, vcol, v_means, v_xy, v_scales, v_quats,
                                               v_sh, v_opac);
 }
@@ -997,9 +1026,18 @@ __global__ __launch_bounds__(kThreads) void k_reduce_view_records_adam(
                                   }
                               });
     const float zero2[2] = {0.f, 0.f}, zero3[3] = {0.f, 0.f, 0.f};
-    store_gradients_or_step<DEG, true, true>(af, n, g0, lane, stage, o.mean, o.scale, o.quat, o.opac, zero2, o.stat_norm,
-                                             o.stat_count, nullptr, zero3, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                             nullptr);
+    // deferred SH: a splat some view saw (stat_count != 0) has its block caught up and stepped, the others wait
+    __shared__ uint32_t row_t0_all[kThreads / kWave][kWave];
+    uint32_t *row_t0 = row_t0_all[wv];
+    const bool seen = af.lazy.on() && g < n && o.stat_count != 0.0f;
+    if (af.lazy.on()) {
+        row_t0[lane] = seen ? af.lazy.sh_time[g] : kInvalid;
+        __builtin_amdgcn_wave_barrier();
+    }
+    store_gradients_or_step<DEG, true, true>(af, n, g0, lane, stage, row_t0, o.mean, o.scale, o.quat, o.opac, zero2,
+                                             o.stat_norm, o.stat_count, nullptr, zero3, nullptr, nullptr, nullptr, nullptr,
+                                             nullptr, nullptr);
+    if (seen) af.lazy.sh_time[g] = af.lazy.now + 1u;
 }
 
 // Dense sum: like the dense backward, the zeros of the splats no view sees are stored straight from registers by the

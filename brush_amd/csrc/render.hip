@@ -541,8 +541,7 @@ extern "C" int brush_reduce_view_records_adam(const float *records, uint32_t num
                                               void *view_index, size_t view_index_bytes, brush_stream_t stream) {
     AdamFuse af{};
     if (!fill_adam_fuse(cfg, means, log_scales, rotation, raw_opacity, sh, n, moment1, moment2, next_quats_fed,
-                        grad_2d_accum, xy_grad_counts, width, height, sh_degree, &af) ||
-        af.lazy.on())  // (the data-parallel reduction steps every block eagerly)
+                        grad_2d_accum, xy_grad_counts, width, height, sh_degree, &af))
         return BRUSH_ERR_INVALID_ARG;
     return reduce_views_impl(records, num_views, rows_per_view, view_rows, view_offsets, campos, means, n, sh_degree,
                              nullptr, nullptr,

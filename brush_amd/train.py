@@ -283,7 +283,9 @@ class SplatTrainer:
             with torch.cuda.device(means.device):
                 _lib.check(l.brush_normalize_quats(quats.data_ptr(), norm_rot.data_ptr(), n, stream), "brush_normalize_quats")
         self.invalidate_cached_rotation()
-        fused = exchange is None and grad_sync is None and self.fused_backward
+        # the optimizer runs inside a kernel that sees which splats the step touches: the single-view fused backward, or
+        # the data-parallel reduction of the views' records (both take BrushAdamConfig.lazy_sh)
+        fused = grad_sync is None and (exchange is not None or self.fused_backward)
         lazy = self._lazy_state(splats, n, ncoef) if fused else None
         if lazy is None:
             self.sync(splats)  # this step reads / steps every SH block: nothing may stay pending

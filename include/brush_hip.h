@@ -291,10 +291,11 @@ typedef struct BrushAdamConfig {
      * statistic the densification threshold is compared with (train.rs:284-316, tuned for B = 1) would shrink B-fold:
      * pass B here to keep the reference's magnitude.  0 is read as 1. */
     float xy_stat_scale;
-    /* Fused forms only (brush_render_backward_adam): NULL, or the deferred-Adam state of the SH block.  The SH
-     * coefficients and moments of splats the view does not see are then left alone (their step stays pending); a
-     * visible splat's block first has its pending steps replayed, then takes this step, and its sh_time becomes
-     * `time`.  Requires lazy_sh->now + 1 == time and 3 C floats per row a multiple of 4 (SH degree 1 or 3). */
+    /* Fused forms only (brush_render_backward_adam, brush_reduce_view_records_adam): NULL, or the deferred-Adam state
+     * of the SH block.  The SH coefficients and moments of splats the view (no view of the batch) sees are then left
+     * alone (their step stays pending); a seen splat's block first has its pending steps replayed, then takes this
+     * step, and its sh_time becomes `time`.  Requires lazy_sh->now + 1 == time and 3 C floats per row a multiple of 4
+     * (SH degree 1 or 3). */
     const BrushLazySh *lazy_sh;
 } BrushAdamConfig;
 /* One Adam step on all five parameter groups in one launch.  v_*: the gradient arrays of

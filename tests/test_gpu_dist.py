@@ -4,6 +4,7 @@ records (brush_render_backward_records), all-gathers them and reduces them with 
 with the dense sum of the two views' gradient blocks, must be BIT-IDENTICAL on the two ranks, and the fused
 sum-into-Adam form must leave the same parameters on both ranks.  The camera backs off between steps so that a view
 outgrows the records buffer after its backward was enqueued (the re-run path)."""
+import math
 import os
 import socket
 
@@ -214,3 +215,76 @@ def test_exchange_survives_refinement_two_ranks_one_gpu():
         assert np.isfinite(params[k]).all()
     assert np.array_equal(m1.view(np.uint32), got[1][4].view(np.uint32))
     assert m1.shape[0] == counts[-1] * (11 + 3 * 4)  # moments laid out for the refined cloud
+
+
+def _deferred_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import brush_amd
+        from brush_amd import dist as BD
+        from brush_amd import render as R
+
+        R.DETERMINISTIC = True  # bitwise reproducible gradients: the two optimizers can be compared bit for bit
+        dev = torch.device("cuda:0")
+        n, w, h, deg = 6000, 160, 96, 3
+        ncoef = (deg + 1) ** 2
+        cloud = H.synthetic_cloud(n, deg, seed=8, mean_mult=0.0003)
+        cloud["log_scales"] = cloud["log_scales"] - 3.5
+        mk = lambda: brush_amd.Splats(*(torch.from_numpy(cloud[k]).to(dev) for k in ("means", "sh", "quats", "raw_opac",
+                                                                                       "log_scales")))
+        a, b = mk(), mk()
+        ta = brush_amd.SplatTrainer(a, brush_amd.TrainConfig(warmup_steps=0, max_refine_step=0, deferred_sh_adam=True))
+        tb = brush_amd.SplatTrainer(b, brush_amd.TrainConfig(warmup_steps=0, max_refine_step=0, deferred_sh_adam=False))
+        xa, xb = BD.ViewExchange(n, ncoef, dev), BD.ViewExchange(n, ncoef, dev)
+        torch.manual_seed(5 + rank)
+        gt = torch.rand((h, w, 3), device=dev)
+        losses, lagged = [], 0
+        for i in range(7):
+            ang = 2.0 * math.pi * ((2 * i + rank) % 5) / 5.0  # the two ranks' views move around the cloud
+            cam = brush_amd.Camera([4.0 * math.sin(ang), 0.0, -4.0 * math.cos(ang)],
+                                   [0.0, -math.sin(ang / 2.0), 0.0, math.cos(ang / 2.0)], 0.4, 0.3, (0.5, 0.5))
+            la, _, _ = ta.step(a, cam, gt, 1.0, world, None, xa)
+            lb, _, _ = tb.step(b, cam, gt, 1.0, world, None, xb)
+            losses.append((float(la), float(lb)))
+            if ta._lazy is not None:
+                lagged = max(lagged, int((ta._lazy_bufs[0] < ta.opt_time).sum()))
+        ta.sync(a)
+        same = {k: bool(torch.equal(getattr(a, k).detach(), getattr(b, k).detach()))
+                for k in ("means", "sh_coeffs", "rotation", "raw_opacity", "log_scales")}
+        same["moment1"] = bool(torch.equal(ta.moment1, tb.moment1))
+        same["moment2"] = bool(torch.equal(ta.moment2, tb.moment2))
+        torch.cuda.synchronize()
+        q.put((rank, losses, lagged, ta._lazy is not None, same, a.sh_coeffs.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_deferred_sh_adam_in_the_view_exchange_two_ranks_one_gpu():
+    """Deferred Adam of the SH block inside the data-parallel reduction (brush_reduce_view_records_adam): the blocks of
+    splats NO view of the batch saw stay pending.  Two ranks, moving views, deterministic mode: the deferred and the
+    eager trainer give the same losses step by step and, after sync(), the same bits in every parameter and moment — on
+    each rank and across the ranks."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_deferred_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=500)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        losses, lagged, was_lazy, same, _ = got[rank]
+        assert was_lazy and lagged > 0, (rank, was_lazy, lagged)
+        assert all(la == lb for la, lb in losses), (rank, losses)
+        assert all(same.values()), (rank, same)
+    assert np.array_equal(got[0][4].view(np.uint32), got[1][4].view(np.uint32))
