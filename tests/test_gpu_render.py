@@ -665,6 +665,17 @@ def test_headline_size_matches_oracle(dev):
     _assert_grad_parity(gpu, orc)
 
 
+def test_dense_scene_matches_oracle(dev):
+    """The bench's dense scene (1 048 576 splats @1920x1080, mean_mult 0.25, SH degree 3: 2.6 M intersections, tile lists
+    of ~320 entries = five LDS batches per tile at one wave per tile) against the oracle and the f64 arbiter."""
+    cloud = H.synthetic_cloud(1 << 20, 3, seed=4, mean_mult=0.25)
+    gpu, orc = _run_pair(dev, cloud, 1920, 1080, 3)
+    V, I = _assert_forward_parity(gpu, orc, 1920, 1080, named=True)
+    _risk_report(orc, "dense")
+    assert V > 100000 and I > 2_000_000
+    _assert_grad_parity(gpu, orc)
+
+
 def _risk_report(orc, tag):
     risk = orc["aux"]["flip_risk"].astype(bool)
     print(f"[{tag}] flip-risk pixels excluded from the 1e-4 / final_index checks: {int(risk.sum())} of {risk.size} "
