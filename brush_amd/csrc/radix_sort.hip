@@ -339,17 +339,44 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
         return;
     }
     // reorder by digit in LDS (stable: wave order, then rank inside the wave) ...
+    if constexpr (kLateVals) {
+        // The late values are requested kValBatch at a time: one at a time (each load followed by its LDS write) the 16
+        // loads of a lane were 16 dependent round trips — 12.7 of the 24 us a 8192-key tile's workgroup lives at 27 M
+        // keys (in-kernel timeline, profiles/r04b_big_sort_timeline.json).  The ballot temporaries are dead by now.
+        constexpr uint32_t kValBatch = THREADS == kSortThreads ? 4 : 16;
 #pragma unroll
-    for (uint32_t i = 0; i < ITEMS; i++) {
-        const uint32_t idx = chunk + i * kWave + lane;
-        if (idx < n) {
-            const uint32_t digit = (key[i] >> shift) & mask;
-            const uint32_t lp = L.tile_start[digit] + L.wave_hist[wid][digit] + rank_of(i);
-            L.keys[lp] = key[i];
-            L.vals[lp] = kLateVals ? (vals_in ? vals_in[idx] : idx) : val[kLateVals ? 0 : i];
+        for (uint32_t i0 = 0; i0 < ITEMS; i0 += kValBatch) {
+            uint32_t v[kValBatch];
+#pragma unroll
+            for (uint32_t u = 0; u < kValBatch; u++) {
+                const uint32_t idx = chunk + (i0 + u) * kWave + lane;
+                v[u] = idx < n ? (vals_in ? vals_in[idx] : idx) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kValBatch; u++) {
+                const uint32_t i = i0 + u, idx = chunk + i * kWave + lane;
+                if (idx < n) {
+                    const uint32_t digit = (key[i] >> shift) & mask;
+                    const uint32_t lp = L.tile_start[digit] + L.wave_hist[wid][digit] + rank_of(i);
+                    L.keys[lp] = key[i];
+                    L.vals[lp] = v[u];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            const uint32_t idx = chunk + i * kWave + lane;
+            if (idx < n) {
+                const uint32_t digit = (key[i] >> shift) & mask;
+                const uint32_t lp = L.tile_start[digit] + L.wave_hist[wid][digit] + rank_of(i);
+                L.keys[lp] = key[i];
+                L.vals[lp] = val[i];
+            }
         }
     }
     __syncthreads();
+    BRUSH_KTRACE_MARK_VIA(trace, 2, L.keys[threadIdx.x]);  // (big tiles: mark 2 is free; reordered in LDS, values loaded)
     // ... and write out: position lp of the reordered tile belongs to the run of its digit, so consecutive lanes
     // write consecutive global addresses (round 1 scattered one dword per lane into 256 runs: 2.1x write
     // amplification at the HBM counters)
@@ -432,14 +459,16 @@ __global__ __launch_bounds__(kBigThreads) void k_sort_downsweep_big(
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ d_n,
     uint32_t max_n, uint32_t shift, uint32_t mask, const uint32_t *__restrict__ counts,
     const uint32_t *__restrict__ totals, uint32_t max_tiles, uint32_t *__restrict__ edges, uint32_t edge_keys) {
+    BRUSH_KTRACE(kTrSortDownBig, shift | ((shift ? 1u : 0u) << 24));
     const uint32_t n = min(*d_n, max_n);
+    BRUSH_KTRACE_MARK(1, n);
     if ((uint64_t)blockIdx.x * kBigTileKeys >= n) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     DownLdsBig &L = *reinterpret_cast<DownLdsBig *>(lds_raw);
     const uint32_t no_spec[kSpecRows] = {};
     downsweep_body<false, kBigTileKeys / kBigThreads, kBigThreads>(keys_in, vals_in, keys_out, vals_out, n, shift,
                                                                    mask, counts, totals, max_tiles, edges, edge_keys, L,
-                                                                   no_spec);
+                                                                   no_spec, BRUSH_KTRACE_REF);
 }
 
 __global__ void k_sort_copy(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,

@@ -24,13 +24,15 @@ from brush_amd import _lib  # noqa: E402
 from brush_amd import render as R  # noqa: E402
 from brush_amd.synthetic import synthetic_cloud  # noqa: E402
 
-CFG = {"S1": (1 << 20, 1920, 1080, 3, 1.0, None), "dense": (1 << 20, 1920, 1080, 3, 0.25, None)}
+CFG = {"S1": (1 << 20, 1920, 1080, 3, 1.0, None), "dense": (1 << 20, 1920, 1080, 3, 0.25, None),
+       "c3": (3_000_000, 1920, 1080, 3, 0.12, 40_000_000)}
 KNAMES = {1: "k_project_cull", 2: "k_compact", 3: "k_sort_upsweep", 4: "k_sort_downsweep", 5: "k_project_visible",
           6: "k_walk_count", 7: "k_scan_reduce", 8: "k_scan_down", 9: "k_map_intersects", 10: "k_rasterize_quad",
           11: "k_zero_compact_grads", 12: "k_rasterize_backward_quad", 13: "k_project_backward", 14: "k_sort_scan",
           15: "k_sort_downsweep_big", 16: "k_sort_onesweep"}
 # what marks 1..4 mean per kernel (segment i = mark i - previous taken stamp)
-MARKS = {1: ["means[0] arrived", "all phase-A loads arrived", "phase A done", "phase B done"],
+MARKS = {15: ["*d_n arrived", "reordered in LDS (values loaded)", "keys arrived (barrier A)", "ranking + scans done (barrier C)"],
+         1: ["means[0] arrived", "all phase-A loads arrived", "phase A done", "phase B done"],
          2: ["block counts summed", "keys arrived", "", ""],
          3: ["*d_n arrived", "first key arrived", "histogram done (2nd barrier)", ""],
          4: ["*d_n arrived", "count table summed", "barrier A + keys arrived", "ranking + scans done (barrier C)"],
