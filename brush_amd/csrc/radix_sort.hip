@@ -274,6 +274,10 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
         else return rank[i];
     };
     const uint64_t lt = lanemask_lt();
+    // digit bits this pass looks at (a 13-bit tile id is sorted as 7 + 6 bits: one and two ballots fewer per key).  Only
+    // in the 1024-thread kernel: measured same box, tile sort 30.4 -> 29.6 us at S1 and 74.3 -> 70.9 on the dense scene,
+    // but the 512-thread large-sort kernel lost 4 us per sort to the extra scalar branches (c3 386 -> 391).
+    const uint32_t nbits = THREADS == kSortThreads ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__popc(mask)) : 8u;
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; i++) {
         const uint32_t idx = chunk + i * kWave + lane;
@@ -282,6 +286,7 @@ __device__ __forceinline__ void downsweep_body(const uint32_t *__restrict__ keys
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (uint32_t b = 0; b < 8; b++) {
+            if (b >= nbits) break;  // wave-uniform
             const bool bit = (digit >> b) & 1u;
             const uint64_t vote = __ballot(valid && bit);
             peers &= bit ? vote : ~vote;
