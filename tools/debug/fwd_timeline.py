@@ -25,7 +25,7 @@ from brush_amd import render as R  # noqa: E402
 from brush_amd.synthetic import synthetic_cloud  # noqa: E402
 
 CFG = {"S1": (1 << 20, 1920, 1080, 3, 1.0, None), "dense": (1 << 20, 1920, 1080, 3, 0.25, None),
-       "c3": (3_000_000, 1920, 1080, 3, 0.12, 40_000_000)}
+       "c3": (3_000_000, 1920, 1080, 3, 0.12, 40_000_000), "S3": (20_971_520, 3840, 2160, 3, 1.0, 24_000_000)}
 KNAMES = {1: "k_project_cull", 2: "k_compact", 3: "k_sort_upsweep", 4: "k_sort_downsweep", 5: "k_project_visible",
           6: "k_walk_count", 7: "k_scan_reduce", 8: "k_scan_down", 9: "k_map_intersects", 10: "k_rasterize_quad",
           11: "k_zero_compact_grads", 12: "k_rasterize_backward_quad", 13: "k_project_backward", 14: "k_sort_scan",
